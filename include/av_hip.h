@@ -1,0 +1,94 @@
+/* C-ABI of libavhip.so — the MI355X (gfx950) kernels behind the audio-visual CTC path.
+ *
+ * The reference (limeorange1102/multimodal-av-model) has no FFI of its own: every device op is a PyTorch /
+ * HuggingFace call.  Each entry point below therefore cites the reference call site (file:line, `hf:` =
+ * transformers/models/wav2vec2/modeling_wav2vec2.py 5.15.0, `torch:` = torch/nn 2.10) whose arithmetic it
+ * replaces.  Conventions:
+ *   - plain pointers + sizes only, no torch types; all buffers are owned by the caller (PyTorch caching
+ *     allocator) and outlive the call; workspaces are passed in;
+ *   - every call enqueues on the given hipStream_t (passed as void*) and returns immediately;
+ *   - return 0 on success, non-zero on error with a message in av_last_error(); never abort();
+ *   - dtype codes: AV_F32 = 0 (parity mode), AV_BF16 = 1 (perf mode).  Accumulation is always fp32.
+ */
+#ifndef AV_HIP_H
+#define AV_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AV_OK 0
+#define AV_ERR_ARG 1
+#define AV_ERR_LAUNCH 2
+
+#define AV_F32 0
+#define AV_BF16 1
+
+/* A-operand addressing modes of av_gemm */
+#define AV_A_ROWMAJOR 0 /* A[m][k] at A + m*lda + k                                   */
+#define AV_A_TRANS 1    /* A[m][k] at A + k*lda + m           (dW = dY^T X)           */
+#define AV_A_CONV2D 2   /* implicit im2col of an NHWC image (ResNet convs, pos-conv)  */
+#define AV_A_CONV3D1 3  /* implicit im2col of a 1-channel [N,T,H,W] volume (front-end) */
+/* B-operand modes */
+#define AV_B_NK 0 /* B[n][k] at B + n*ldb + k  (nn.Linear weight layout)  */
+#define AV_B_KN 1 /* B[k][n] at B + k*ldb + n                             */
+/* epilogue activation */
+#define AV_ACT_NONE 0
+#define AV_ACT_GELU 1          /* v = gelu(v)                     hf:565-572, hf:291-299 */
+#define AV_ACT_MUL_GELU_GRAD 2 /* v = v * gelu'(aux[m][n])        backward of the above  */
+
+const char* av_last_error(void);
+int av_version(void);
+
+/* ---- MFMA GEMM family: C = epilogue(alpha * A x B) ------------------------------------------------------
+ * replaces: nn.Linear (hf:522-527,546,565-572,429-434; model/fusion_module.py:57-58,63; model/decoder.py:24),
+ * F.conv1d of the wav2vec2 feature encoder layers 1-6 as a strided GEMM (hf:291-299), the grouped positional
+ * conv (hf:360-368), nn.Conv2d of the ResNet trunk (model/encoder.py:9-12,36), nn.Conv3d front-end
+ * (model/encoder.py:61), and all the dX / dW products of their backward passes.
+ * epilogue, in order: v = alpha*acc; v += bias[n]; C2[m][n] = v (optional pre-activation copy);
+ * act; v += R[m][n] (fp32 residual, may alias C); C[m][n] = v;  optional per-column sum / sum-of-squares
+ * partials for train-mode BatchNorm statistics (model/trainer.py:54): stats[blockRow][0/1][n].               */
+typedef struct av_gemm_args {
+    const void* A;
+    const void* B;
+    void* C;
+    void* C2;          /* optional, same dtype/ld as C */
+    const float* bias; /* optional [N] */
+    const float* R;    /* optional fp32 residual, ld = ldr */
+    const void* aux;   /* AV_ACT_MUL_GELU_GRAD operand, dtype = aux_dtype, ld = ldc */
+    float* stats;      /* optional [ceil(M/128)][2][N] fp32 partials (batch must be 1) */
+    int M, N, K, batch;
+    long long lda, ldb, ldc, ldr;
+    long long sA, sB, sC, sR; /* batch strides in elements */
+    int a_mode, b_mode, in_dtype, out_dtype, aux_dtype, act;
+    float alpha;
+    /* implicit-im2col geometry (a_mode 2/3): input [img][T][H][W][Ctot] (T = 1 for 2-D) */
+    int cT, cH, cW, cCtot, cCin, cCoff;
+    int cKt, cKh, cKw, cSh, cSw, cPt, cPh, cPw, cOh, cOw;
+} av_gemm_args;
+int av_gemm(const av_gemm_args* args, void* stream);
+
+/* ---- row kernels (one wavefront per row, shuffle reductions) ------------------------------------------- */
+/* nn.LayerNorm over the last dim (hf:297,431,638,644,791), eps 1e-5, optional exact-erf GELU (hf:298).
+ * x [rows][cols] (dtype xdt), y (dtype ydt); mean/rstd [rows] fp32 optional (saved for backward). */
+int av_layernorm_fwd(const void* x, int xdt, const float* gamma, const float* beta, void* y, int ydt,
+                     float* mean, float* rstd, long long rows, int cols, float eps, int act, void* stream);
+/* dx = dres + LN'(dy) (dres optional fp32); dgamma/dbeta partials [nblk][2][cols] (optional; reduce with
+ * av_colsum). x fp32/bf16 (xdt), dy dtype dydt, dx fp32. */
+int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
+                     const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk,
+                     long long rows, int cols, void* stream);
+/* F.log_softmax(dim=-1) (model/decoder.py:25) and its backward: dx = dy - exp(y) * sum(dy) */
+int av_log_softmax_fwd(const void* x, int xdt, float* y, long long rows, int cols, void* stream);
+int av_log_softmax_bwd(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, void* stream);
+/* column sums of a [rows][cols] matrix (bias gradients): out[cols] (+)= sum_rows x */
+int av_colsum(const void* x, int xdt, float* out, long long rows, int cols, long long ld, int accumulate,
+              void* stream);
+/* elementwise */
+int av_cast(const void* x, int xdt, void* y, int ydt, long long n, void* stream);
+int av_axpby(float a, const void* x, int xdt, float b, float* y, long long n, void* stream); /* y = a*x + b*y */
+int av_mask_rows(void* x, int xdt, const unsigned char* keep, long long rows, int cols, void* stream); /* hf:752-755 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

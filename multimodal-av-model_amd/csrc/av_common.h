@@ -1,0 +1,73 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the audio-visual CTC path.
+// Wavefront = 64 lanes; MFMA 16x16 tiles; all kernels enqueue on the caller's hipStream_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/av_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define AV_WAVE 64
+
+// ---- error plumbing (never abort; python turns a non-zero status into RuntimeError) ----
+void av_set_error(const char* fmt, ...);
+#define AV_CHECK(cond, ...)                         \
+    do {                                            \
+        if (!(cond)) {                              \
+            av_set_error(__VA_ARGS__);              \
+            return AV_ERR_ARG;                      \
+        }                                           \
+    } while (0)
+#define AV_LAUNCH_CHECK()                                                        \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            av_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return AV_ERR_LAUNCH;                                                \
+        }                                                                        \
+    } while (0)
+
+// ---- scalar conversions ----
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// dtype-erased element load/store (dtype: AV_F32 / AV_BF16)
+__device__ __forceinline__ float ld_any(const void* p, long long i, int dtype) {
+    return dtype == AV_F32 ? ((const float*)p)[i] : (float)((const bf16_t*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, long long i, int dtype, float v) {
+    if (dtype == AV_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = (bf16_t)v;
+}
+
+// ---- wave / block reductions (64-lane wavefront) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU and its derivative — transformers/activations.py "gelu" 
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+static inline int av_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

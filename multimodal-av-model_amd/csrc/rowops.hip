@@ -1,0 +1,295 @@
+// Row-wise kernels: one 64-lane wavefront per row, shuffle reductions (no LDS for the row reduce).
+// LayerNorm fwd/bwd (+GELU), log_softmax fwd/bwd, column sums (bias gradients), casts, axpby, row masking.
+// All HBM-bound: each element is read once (rows are cached in registers between the passes).
+#include "av_common.h"
+
+namespace {
+
+constexpr int MAXIT = 32;  // 64 lanes x 32 = rows up to 2048 columns
+
+template <int ACT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, int xdt, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, void* __restrict__ y, int ydt,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     long long rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long base = row * cols;
+    float v[MAXIT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        v[it] = c < cols ? ld_any(x, base + c, xdt) : 0.f;
+        s += v[it];
+    }
+    const float mean = wave_sum(s) / cols;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        const float d = c < cols ? v[it] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        if (c < cols) {
+            float o = (v[it] - mean) * rstd * gamma[c] + beta[c];
+            if (ACT == AV_ACT_GELU) o = gelu_f(o);
+            st_any(y, base + c, ydt, o);
+        }
+    }
+    if (lane == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (rstd_o) rstd_o[row] = rstd;
+    }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, int xdt, const void* __restrict__ dy, int dydt,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ dgb, long long rows, int cols,
+                                                     long long rows_per_block) {
+    __shared__ float red[4][2][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    long long r_end = r_begin + rows_per_block;
+    if (r_end > rows) r_end = rows;
+    float dg[MAXIT], db[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) { dg[it] = 0.f; db[it] = 0.f; }
+    for (long long row = r_begin + w; row < r_end; row += 4) {
+        const long long base = row * cols;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[MAXIT], g[MAXIT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = lane + 64 * it;
+            if (c < cols) {
+                const float d = ld_any(dy, base + c, dydt);
+                xh[it] = (ld_any(x, base + c, xdt) - mu) * rs;
+                g[it] = d * gamma[c];
+                dg[it] += d * xh[it];
+                db[it] += d;
+                s1 += g[it];
+                s2 += g[it] * xh[it];
+            } else { xh[it] = 0.f; g[it] = 0.f; }
+        }
+        s1 = wave_sum(s1) / cols;
+        s2 = wave_sum(s2) / cols;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = lane + 64 * it;
+            if (c < cols) {
+                float o = rs * (g[it] - s1 - xh[it] * s2);
+                if (dres) o += dres[base + c];
+                dx[base + c] = o;
+            }
+        }
+    }
+    if (dgb) {   // combine the 4 waves, write [blk][2][cols]
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            if (64 * it >= cols) break;
+            red[w][0][lane] = dg[it];
+            red[w][1][lane] = db[it];
+            __syncthreads();
+            if (w == 0) {
+                const int c = lane + 64 * it;
+                if (c < cols) {
+                    float* o = dgb + (long long)blockIdx.x * 2 * cols;
+                    o[c] = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
+                    o[cols + c] = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lsm_fwd_kernel(const void* __restrict__ x, int xdt, float* __restrict__ y, long long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long base = row * cols;
+    float v[MAXIT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        v[it] = c < cols ? ld_any(x, base + c, xdt) : -INFINITY;
+        mx = fmaxf(mx, v[it]);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        if (c < cols) s += expf(v[it] - mx);
+    }
+    const float lse = mx + logf(wave_sum(s));
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        if (c < cols) y[base + c] = v[it] - lse;
+    }
+}
+
+__global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, void* __restrict__ dx,
+                                                      int dxdt, long long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long base = row * cols;
+    float d[MAXIT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        d[it] = c < cols ? dy[base + c] : 0.f;
+        s += d[it];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        if (c < cols) st_any(dx, base + c, dxdt, d[it] - expf(y[base + c]) * s);
+    }
+}
+
+constexpr int CS_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int xdt, float* __restrict__ out, long long rows,
+                                                     int cols, long long ld) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long r0 = (long long)blockIdx.y * CS_ROWS;
+    long long r1 = r0 + CS_ROWS;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    if (c < cols)
+        for (long long r = r0 + ry; r < r1; r += 4) s += ld_any(x, r * ld + c, xdt);
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < cols) atomicAdd(out + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+
+__global__ void cast_kernel(const void* __restrict__ x, int xdt, void* __restrict__ y, int ydt, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        st_any(y, i, ydt, ld_any(x, i, xdt));
+}
+__global__ void cast_f32_bf16_vec(const float4* __restrict__ x, bf16x4* __restrict__ y, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        bf16x4 o; o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+        y[i] = o;
+    }
+}
+__global__ void axpby_kernel(float a, const void* __restrict__ x, int xdt, float b, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = a * ld_any(x, i, xdt) + (b == 0.f ? 0.f : b * y[i]);
+}
+__global__ void mask_rows_kernel(void* __restrict__ x, int xdt, const unsigned char* __restrict__ keep, long long rows, int cols) {
+    const long long n = rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (!keep[i / cols]) st_any(x, i, xdt, 0.f);
+}
+
+inline int ew_grid(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int av_layernorm_fwd(const void* x, int xdt, const float* gamma, const float* beta, void* y, int ydt, float* mean,
+                                float* rstd, long long rows, int cols, float eps, int act, void* stream) {
+    AV_CHECK(x && gamma && beta && y, "av_layernorm_fwd: null pointer");
+    AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_layernorm_fwd: cols=%d out of range (1..%d)", cols, 64 * MAXIT);
+    AV_CHECK(act == AV_ACT_NONE || act == AV_ACT_GELU, "av_layernorm_fwd: bad act %d", act);
+    if (rows == 0) return AV_OK;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (act == AV_ACT_GELU)
+        hipLaunchKernelGGL(ln_fwd_kernel<AV_ACT_GELU>, grid, dim3(256), 0, (hipStream_t)stream, x, xdt, gamma, beta, y, ydt, mean, rstd, rows, cols, eps);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<AV_ACT_NONE>, grid, dim3(256), 0, (hipStream_t)stream, x, xdt, gamma, beta, y, ydt, mean, rstd, rows, cols, eps);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
+                                const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk, long long rows,
+                                int cols, void* stream) {
+    AV_CHECK(x && dy && gamma && mean && rstd && dx, "av_layernorm_bwd: null pointer");
+    AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_layernorm_bwd: cols=%d out of range", cols);
+    AV_CHECK(nblk >= 1, "av_layernorm_bwd: nblk=%d", nblk);
+    if (rows == 0) return AV_OK;
+    const long long rpb = (rows + nblk - 1) / nblk;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx,
+                       dgb_partial, rows, cols, rpb);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_log_softmax_fwd(const void* x, int xdt, float* y, long long rows, int cols, void* stream) {
+    AV_CHECK(x && y, "av_log_softmax_fwd: null pointer");
+    AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_log_softmax_fwd: cols=%d out of range", cols);
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(lsm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, xdt, y, rows, cols);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_log_softmax_bwd(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, void* stream) {
+    AV_CHECK(y && dy && dx, "av_log_softmax_bwd: null pointer");
+    AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_log_softmax_bwd: cols=%d out of range", cols);
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(lsm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, dxdt, rows, cols);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_colsum(const void* x, int xdt, float* out, long long rows, int cols, long long ld, int accumulate, void* stream) {
+    AV_CHECK(x && out, "av_colsum: null pointer");
+    AV_CHECK(cols > 0 && ld >= cols, "av_colsum: cols=%d ld=%lld", cols, ld);
+    if (!accumulate) {
+        if (hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream) != hipSuccess) { av_set_error("av_colsum: memset failed"); return AV_ERR_LAUNCH; }
+    }
+    if (rows == 0) return AV_OK;
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + CS_ROWS - 1) / CS_ROWS));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xdt, out, rows, cols, ld);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_cast(const void* x, int xdt, void* y, int ydt, long long n, void* stream) {
+    AV_CHECK(x && y, "av_cast: null pointer");
+    if (n == 0) return AV_OK;
+    if (xdt == AV_F32 && ydt == AV_BF16 && n % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 8 == 0)
+        hipLaunchKernelGGL(cast_f32_bf16_vec, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (bf16x4*)y, n / 4);
+    else
+        hipLaunchKernelGGL(cast_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, xdt, y, ydt, n);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_axpby(float a, const void* x, int xdt, float b, float* y, long long n, void* stream) {
+    AV_CHECK(x && y, "av_axpby: null pointer");
+    if (n == 0) return AV_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, x, xdt, b, y, n);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_mask_rows(void* x, int xdt, const unsigned char* keep, long long rows, int cols, void* stream) {
+    AV_CHECK(x && keep, "av_mask_rows: null pointer");
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, xdt, keep, rows, (int)cols);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
