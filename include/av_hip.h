@@ -58,7 +58,7 @@ typedef struct av_gemm_args {
     float* stats;      /* optional [ceil(M/128)][2][N] fp32 partials (batch must be 1) */
     int M, N, K, batch;
     long long lda, ldb, ldc, ldr;
-    long long sA, sB, sC, sR; /* batch strides in elements */
+    long long sA, sB, sC, sR, sBias; /* batch strides in elements */
     int a_mode, b_mode, in_dtype, out_dtype, aux_dtype, act;
     float alpha;
     /* implicit-im2col geometry (a_mode 2/3): input [img][T][H][W][Ctot] (T = 1 for 2-D) */

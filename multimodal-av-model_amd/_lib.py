@@ -1,0 +1,74 @@
+"""ctypes binding of libavhip.so (include/av_hip.h).  Fails loudly: there is NO CPU / PyTorch fallback.
+
+The library is built in-tree by ``build.py`` (hipcc, gfx950) and travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavhip.so")
+
+AV_F32, AV_BF16 = 0, 1
+A_ROWMAJOR, A_TRANS, A_CONV2D, A_CONV3D1 = 0, 1, 2, 3
+B_NK, B_KN = 0, 1
+ACT_NONE, ACT_GELU, ACT_MUL_GELU_GRAD = 0, 1, 2
+
+vp, ll, i32, f32 = C.c_void_p, C.c_longlong, C.c_int, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("bias", vp), ("R", vp), ("aux", vp), ("stats", vp),
+        ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
+        ("lda", ll), ("ldb", ll), ("ldc", ll), ("ldr", ll),
+        ("sA", ll), ("sB", ll), ("sC", ll), ("sR", ll), ("sBias", ll),
+        ("a_mode", i32), ("b_mode", i32), ("in_dtype", i32), ("out_dtype", i32), ("aux_dtype", i32), ("act", i32),
+        ("alpha", f32),
+        ("cT", i32), ("cH", i32), ("cW", i32), ("cCtot", i32), ("cCin", i32), ("cCoff", i32),
+        ("cKt", i32), ("cKh", i32), ("cKw", i32), ("cSh", i32), ("cSw", i32), ("cPt", i32), ("cPh", i32), ("cPw", i32),
+        ("cOh", i32), ("cOw", i32),
+    ]
+
+
+# name -> argtypes (restype is int status unless listed in _RESTYPES); must list every symbol of include/av_hip.h
+SIGNATURES = {
+    "av_last_error": [],
+    "av_version": [],
+    "av_gemm": [C.POINTER(GemmArgs), vp],
+    "av_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, ll, i32, f32, i32, vp],
+    "av_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp],
+    "av_log_softmax_fwd": [vp, i32, vp, ll, i32, vp],
+    "av_log_softmax_bwd": [vp, vp, vp, i32, ll, i32, vp],
+    "av_colsum": [vp, i32, vp, ll, i32, ll, i32, vp],
+    "av_cast": [vp, i32, vp, i32, ll, vp],
+    "av_axpby": [f32, vp, i32, f32, vp, ll, vp],
+    "av_mask_rows": [vp, i32, vp, ll, i32, vp],
+}
+_RESTYPES = {"av_last_error": C.c_char_p}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raise if it is missing — no fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python {os.path.join(_HERE, 'build.py')}` "
+                "(hipcc --offload-arch=gfx950). The MI355X path has no CPU/PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)           # AttributeError if a declared symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().av_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libavhip {what} failed (status {status}): {msg}")

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const av_gemm_args p, const in
     for (int j = 0; j < WN_T; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 16 + r;
         const bool nok = n < p.N;
-        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        const float bias = (p.bias && nok) ? p.bias[(long long)z * p.sBias + n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll

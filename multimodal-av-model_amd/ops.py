@@ -1,0 +1,191 @@
+"""Torch-tensor wrappers over the C-ABI of libavhip.so (plumbing only: pointers, shapes, current stream).
+
+PyTorch provides device memory and streams; every arithmetic op on the path is a HIP kernel of ours.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import AV_BF16, AV_F32
+
+Tensor = torch.Tensor
+
+
+def dt(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return AV_F32
+    if t.dtype == torch.bfloat16:
+        return AV_BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (libavhip handles float32 / bfloat16)")
+
+
+def tdt(code: int) -> torch.dtype:
+    return torch.float32 if code == AV_F32 else torch.bfloat16
+
+
+def ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor must live on the GPU (no CPU fallback in libavhip)")
+
+
+def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
+         a_mode: int = L.A_ROWMAJOR, b_mode: int = L.B_NK, bias: Optional[Tensor] = None, act: int = L.ACT_NONE,
+         R: Optional[Tensor] = None, ldr: int = 0, aux: Optional[Tensor] = None, C2: Optional[Tensor] = None,
+         stats: Optional[Tensor] = None, alpha: float = 1.0, batch: int = 1, sA: int = 0, sB: int = 0, sC: int = 0,
+         sR: int = 0, sBias: int = 0, conv: Optional[dict] = None, a_off: int = 0, b_off: int = 0, c_off: int = 0) -> Tensor:
+    """Raw av_gemm call.  Offsets are in elements."""
+    _req(A, "gemm A"); _req(B, "gemm B"); _req(C_, "gemm C")
+    if A.dtype != B.dtype:
+        raise TypeError(f"gemm: A {A.dtype} and B {B.dtype} must match")
+    a = L.GemmArgs()
+    a.A = A.data_ptr() + a_off * A.element_size()
+    a.B = B.data_ptr() + b_off * B.element_size()
+    a.C = C_.data_ptr() + c_off * C_.element_size()
+    a.C2 = ptr(C2) if C2 is None else C2.data_ptr() + c_off * C2.element_size()
+    a.bias = ptr(bias); a.R = ptr(R) if R is None else R.data_ptr() + c_off * 4
+    a.aux = ptr(aux); a.stats = ptr(stats)
+    a.M, a.N, a.K, a.batch = M, N, K, batch
+    a.lda, a.ldb, a.ldc, a.ldr = lda, ldb, ldc, (ldr or ldc)
+    a.sA, a.sB, a.sC, a.sR, a.sBias = sA, sB, sC, sR, sBias
+    a.a_mode, a.b_mode = a_mode, b_mode
+    a.in_dtype, a.out_dtype = dt(A), dt(C_)
+    a.aux_dtype = dt(aux) if aux is not None else 0
+    a.act, a.alpha = act, alpha
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("gemm: bias must be float32")
+    if R is not None and R.dtype != torch.float32:
+        raise TypeError("gemm: residual must be float32")
+    if conv:
+        for k, v in conv.items():
+            setattr(a, k, v)
+    L.check(L.lib().av_gemm(C.byref(a), stream()), "av_gemm")
+    return C_
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, out_dtype: Optional[torch.dtype] = None,
+           act: int = L.ACT_NONE, R: Optional[Tensor] = None, out: Optional[Tensor] = None, C2: Optional[Tensor] = None,
+           aux: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+    """y[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias)  (nn.Linear layout).  x may be any [..., K] contiguous tensor."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape[1] == K and x.is_contiguous() and w.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype or x.dtype, device=x.device)
+    gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, R=R, aux=aux, C2=C2, alpha=alpha)
+    return out
+
+
+def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, act: int = L.ACT_NONE,
+              aux: Optional[Tensor] = None, R: Optional[Tensor] = None, out: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+    """y[M,N] = a[M,K] @ b[K,N]  (b row-major, e.g. dX = dY @ W with W [N_out,K_in])."""
+    K = a.shape[-1]
+    M = a.numel() // K
+    N = b.shape[1]
+    assert b.shape[0] == K and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (N,), dtype=out_dtype or a.dtype, device=a.device)
+    gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_mode=L.B_KN, act=act, aux=aux, R=R, alpha=alpha)
+    return out
+
+
+def matmul_tn(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, alpha: float = 1.0, accumulate: bool = False) -> Tensor:
+    """y[M,N] (fp32) = a[K,M]^T @ b[K,N]   (dW = dY^T X: a = dY [tokens, out], b = X [tokens, in])."""
+    Kk, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == Kk and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    gemm(a, b, out, M=M, N=N, K=Kk, lda=M, ldb=N, ldc=N, a_mode=L.A_TRANS, b_mode=L.B_KN, alpha=alpha,
+         R=out if accumulate else None)
+    return out
+
+
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, *, out_dtype: torch.dtype, eps: float = 1e-5, act: int = L.ACT_NONE,
+                  save_stats: bool = False):
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.lib().av_layernorm_fwd(ptr(x), dt(x), ptr(gamma), ptr(beta), ptr(y), dt(y), ptr(mean), ptr(rstd), rows, cols,
+                                     eps, act, stream()), "av_layernorm_fwd")
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
+                  want_param_grads: bool = False):
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    nblk = max(1, min(512, (rows + 15) // 16))
+    part = torch.empty((nblk, 2 * cols), dtype=torch.float32, device=x.device) if want_param_grads else None
+    L.check(L.lib().av_layernorm_bwd(ptr(x), dt(x), ptr(dy), dt(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                                     ptr(part), nblk, rows, cols, stream()), "av_layernorm_bwd")
+    if want_param_grads:
+        gb = colsum(part)
+        return dx, gb[:cols], gb[cols:]
+    return dx
+
+
+def log_softmax_fwd(x: Tensor) -> Tensor:
+    cols = x.shape[-1]
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    L.check(L.lib().av_log_softmax_fwd(ptr(x), dt(x), ptr(y), x.numel() // cols, cols, stream()), "av_log_softmax_fwd")
+    return y
+
+
+def log_softmax_bwd(y: Tensor, dy: Tensor, out_dtype: torch.dtype) -> Tensor:
+    cols = y.shape[-1]
+    dx = torch.empty(y.shape, dtype=out_dtype, device=y.device)
+    L.check(L.lib().av_log_softmax_bwd(ptr(y), ptr(dy), ptr(dx), dt(dx), y.numel() // cols, cols, stream()), "av_log_softmax_bwd")
+    return dx
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+        accumulate = False
+    L.check(L.lib().av_colsum(ptr(x), dt(x), ptr(out), rows, cols, cols, int(accumulate), stream()), "av_colsum")
+    return out
+
+
+def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
+    if x.dtype == dtype:
+        return x
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.lib().av_cast(ptr(x), dt(x), ptr(y), dt(y), x.numel(), stream()), "av_cast")
+    return y
+
+
+def axpby(a: float, x: Tensor, b: float, y: Tensor) -> Tensor:
+    """y = a*x + b*y  (y fp32, in place)."""
+    assert x.is_contiguous() and y.is_contiguous() and y.dtype == torch.float32 and x.numel() == y.numel()
+    L.check(L.lib().av_axpby(a, ptr(x), dt(x), b, ptr(y), x.numel(), stream()), "av_axpby")
+    return y
+
+
+def mask_rows_(x: Tensor, keep_u8: Tensor) -> Tensor:
+    cols = x.shape[-1]
+    L.check(L.lib().av_mask_rows(ptr(x), dt(x), ptr(keep_u8), x.numel() // cols, cols, stream()), "av_mask_rows")
+    return x

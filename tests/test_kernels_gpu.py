@@ -1,0 +1,179 @@
+"""GPU parity of the individual HIP kernels (through the C-ABI) against plain PyTorch fp64/fp32 references."""
+import math
+
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+ops = None
+L = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _load():
+    global ops, L
+    ops = pkg("ops")
+    L = pkg("_lib")
+    L.lib()
+    assert torch.cuda.is_available()
+    torch.manual_seed(0)
+
+
+def _tol(dtype):
+    return dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+def _rand(*shape, dtype=torch.float32, scale=1.0):
+    return (torch.randn(*shape, device="cuda", dtype=torch.float32) * scale).to(dtype)
+
+
+def _ref_mm(a, b):
+    return (a.double() @ b.double()).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (100, 70, 50), (257, 129, 95), (64, 2048, 512), (300, 64, 64), (1, 800, 1024),
+                                   (199, 1024, 1024), (513, 48, 40)])
+def test_linear_shapes(dtype, M, N, K):
+    x = _rand(M, K, dtype=dtype); w = _rand(N, K, dtype=dtype, scale=1 / math.sqrt(K)); b = _rand(N)
+    y = ops.linear(x, w, b, out_dtype=torch.float32)
+    ref = _ref_mm(x, w.t()) + b
+    torch.testing.assert_close(y, ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mfma_layout_identity_asymmetric(dtype):
+    """A = I with an asymmetric B catches swapped row/col maps (guide §3)."""
+    n = 128
+    a = torch.eye(n, device="cuda").to(dtype)
+    w = (torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n) % 251 - 125).to(dtype)  # w[n][k]
+    y = ops.linear(a, w, None, out_dtype=torch.float32)
+    torch.testing.assert_close(y, w.float().t().contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_epilogues(dtype):
+    M, N, K = 200, 192, 160
+    x = _rand(M, K, dtype=dtype); w = _rand(N, K, dtype=dtype, scale=1 / math.sqrt(K)); b = _rand(N)
+    r = _rand(M, N)
+    pre = torch.empty(M, N, device="cuda", dtype=dtype)
+    y = ops.linear(x, w, b, out_dtype=dtype, act=L.ACT_GELU, C2=pre)
+    ref_pre = _ref_mm(x, w.t()) + b
+    torch.testing.assert_close(pre.float(), ref_pre, **_tol(dtype))
+    torch.testing.assert_close(y.float(), torch.nn.functional.gelu(ref_pre), **_tol(dtype))
+    # residual (aliasing C) + alpha
+    out = r.clone()
+    ops.linear(x, w, b, out=out, R=out, alpha=0.5)
+    torch.testing.assert_close(out, 0.5 * _ref_mm(x, w.t()) + b + r, **_tol(dtype))
+    # gelu-grad multiply
+    u = _rand(M, N, dtype=dtype)
+    g = ops.linear(x, w, None, out_dtype=torch.float32, act=L.ACT_MUL_GELU_GRAD, aux=u)
+    uu = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(uu).sum().backward()
+    torch.testing.assert_close(g, _ref_mm(x, w.t()) * uu.grad, **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(130, 96, 200), (64, 64, 64), (257, 1024, 129), (200, 70, 33)])
+def test_matmul_nn_tn(dtype, M, N, K):
+    a = _rand(M, K, dtype=dtype); b = _rand(K, N, dtype=dtype, scale=1 / math.sqrt(K))
+    torch.testing.assert_close(ops.matmul_nn(a, b, out_dtype=torch.float32), _ref_mm(a, b), **_tol(dtype))
+    at = _rand(K, M, dtype=dtype, scale=1 / math.sqrt(K))           # [K,M]^T @ [K,N]
+    torch.testing.assert_close(ops.matmul_tn(at, b), _ref_mm(at.t(), b), **_tol(dtype))
+    acc = _rand(M, N)
+    ref = acc + 2.0 * _ref_mm(at.t(), b)
+    ops.matmul_tn(at, b, out=acc, alpha=2.0, accumulate=True)
+    torch.testing.assert_close(acc, ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_strided_gemm(dtype):
+    """QK^T-style batched product with head-strided operands."""
+    Bz, T, H, D = 3, 70, 4, 32
+    qkv = _rand(Bz, T, 3 * H * D, dtype=dtype)
+    out = torch.empty(Bz * H, T, T, device="cuda", dtype=torch.float32)
+    for b in range(Bz):     # batch over heads inside one call per batch item
+        ops.gemm(qkv, qkv, out, M=T, N=T, K=D, lda=3 * H * D, ldb=3 * H * D, ldc=T, batch=H, sA=D, sB=D, sC=T * T,
+                 a_off=b * T * 3 * H * D, b_off=b * T * 3 * H * D + H * D, c_off=b * H * T * T, alpha=0.125)
+    q = qkv[..., : H * D].float().view(Bz, T, H, D).transpose(1, 2)
+    k = qkv[..., H * D: 2 * H * D].float().view(Bz, T, H, D).transpose(1, 2)
+    ref = (q.double() @ k.double().transpose(2, 3)).float().reshape(Bz * H, T, T) * 0.125
+    torch.testing.assert_close(out, ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cin,Cout,H,stride,k", [(64, 64, 12, 1, 3), (64, 128, 12, 2, 3), (64, 128, 12, 2, 1), (128, 64, 6, 1, 3)])
+def test_conv2d_implicit_gemm(dtype, Cin, Cout, H, stride, k):
+    N_ = 5
+    pad = k // 2
+    x = _rand(N_, H, H, Cin, dtype=dtype)                       # NHWC
+    w = _rand(Cout, Cin, k, k, dtype=dtype, scale=1 / math.sqrt(Cin * k * k))
+    wk = w.permute(0, 2, 3, 1).contiguous().view(Cout, k * k * Cin)
+    Ho = (H + 2 * pad - k) // stride + 1
+    M = N_ * Ho * Ho
+    out = torch.empty(M, Cout, device="cuda", dtype=torch.float32)
+    nblk = (M + 127) // 128
+    stats = torch.zeros(nblk, 2, Cout, device="cuda")
+    conv = dict(cT=1, cH=H, cW=H, cCtot=Cin, cCin=Cin, cCoff=0, cKt=1, cKh=k, cKw=k, cSh=stride, cSw=stride, cPt=0, cPh=pad, cPw=pad,
+                cOh=Ho, cOw=Ho)
+    ops.gemm(x, wk, out, M=M, N=Cout, K=k * k * Cin, lda=0, ldb=k * k * Cin, ldc=Cout, a_mode=L.A_CONV2D, conv=conv, stats=stats)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2).double(), w.double(), None, stride, pad).float().permute(0, 2, 3, 1).reshape(M, Cout)
+    torch.testing.assert_close(out, ref, **_tol(dtype))
+    torch.testing.assert_close(stats[:, 0].sum(0), out.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(stats[:, 1].sum(0), (out * out).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_frontend_gather(dtype):
+    B, T, H = 2, 6, 20
+    x = _rand(B, T, H, H, dtype=dtype)
+    w = _rand(64, 1, 5, 7, 7, dtype=dtype, scale=1 / math.sqrt(245))
+    Ho = (H + 6 - 7) // 2 + 1
+    M = B * T * Ho * Ho
+    out = torch.empty(M, 64, device="cuda", dtype=torch.float32)
+    conv = dict(cT=T, cH=H, cW=H, cCtot=1, cCin=1, cCoff=0, cKt=5, cKh=7, cKw=7, cSh=2, cSw=2, cPt=2, cPh=3, cPw=3, cOh=Ho, cOw=Ho)
+    ops.gemm(x, w.view(64, 245).contiguous(), out, M=M, N=64, K=245, lda=0, ldb=245, ldc=64, a_mode=L.A_CONV3D1, conv=conv)
+    ref = torch.nn.functional.conv3d(x.float()[:, None].double(), w.double(), None, (1, 2, 2), (2, 3, 3)).float()
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(M, 64)
+    torch.testing.assert_close(out, ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cols", [32, 64, 512, 1024, 800])
+def test_layernorm_fwd_bwd(xdt, cols):
+    rows = 77
+    x = _rand(rows, cols, dtype=xdt); g = 1 + 0.1 * _rand(cols); b = 0.1 * _rand(cols)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, out_dtype=torch.float32, save_stats=True)
+    xr = x.float().requires_grad_(True); gr = g.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (cols,), gr, br, 1e-5)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+    yg = ops.layernorm_fwd(x, g, b, out_dtype=torch.float32, act=L.ACT_GELU)
+    torch.testing.assert_close(yg, torch.nn.functional.gelu(ref), rtol=1e-5, atol=1e-5)
+    dy = _rand(rows, cols); dres = _rand(rows, cols)
+    ref.backward(dy)
+    dx, dg, db = ops.layernorm_bwd(x, dy, g, mean, rstd, dres, want_param_grads=True)
+    torch.testing.assert_close(dx, xr.grad + dres, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dg, gr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db, br.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_log_softmax_colsum_cast():
+    x = _rand(51, 800, scale=3.0)
+    y = ops.log_softmax_fwd(x)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.log_softmax(xr, -1)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+    dy = _rand(51, 800)
+    ref.backward(dy)
+    torch.testing.assert_close(ops.log_softmax_bwd(y, dy, torch.float32), xr.grad, rtol=1e-5, atol=1e-5)
+    big = _rand(1300, 200)
+    torch.testing.assert_close(ops.colsum(big), big.sum(0), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ops.cast(big, torch.bfloat16), big.to(torch.bfloat16), rtol=0, atol=0)
+    z = _rand(1300, 200)
+    torch.testing.assert_close(ops.axpby(2.0, big, 0.5, z.clone()), 2 * big + 0.5 * z)
+    keep = (torch.rand(1300, device="cuda") > 0.3).to(torch.uint8)
+    m = ops.mask_rows_(big.clone(), keep)
+    torch.testing.assert_close(m, big * keep[:, None].float())
