@@ -64,6 +64,9 @@ typedef struct av_gemm_args {
     /* implicit-im2col geometry (a_mode 2/3): input [img][T][H][W][Ctot] (T = 1 for 2-D) */
     int cT, cH, cW, cCtot, cCin, cCoff;
     int cKt, cKh, cKw, cSh, cSw, cPt, cPh, cPw, cOh, cOw;
+    /* optional two-level batch: z = zo*batch_inner + zi; offsets zo*o? + zi*s? (batch_inner = 0: one level) */
+    int batch_inner;
+    long long oA, oB, oC;
 } av_gemm_args;
 int av_gemm(const av_gemm_args* args, void* stream);
 
@@ -87,6 +90,20 @@ int av_colsum(const void* x, int xdt, float* out, long long rows, int cols, long
 int av_cast(const void* x, int xdt, void* y, int ydt, long long n, void* stream);
 int av_axpby(float a, const void* x, int xdt, float b, float* y, long long n, void* stream); /* y = a*x + b*y */
 int av_mask_rows(void* x, int xdt, const unsigned char* keep, long long rows, int cols, void* stream); /* hf:752-755 */
+
+/* ---- fused attention (flash-style forward) ---------------------------------------------------------------
+ * O = softmax(scale*Q K^T + key-padding mask) V, LSE saved.  Replaces hf:438-463 (sdpa, 16 heads x 64) and the
+ * need_weights path of nn.MultiheadAttention (torch:functional.py:6576-6606; fusion_module.py:61, 4 heads x 128).
+ * Element (b, t, h, d) of Q at q + b*q_bs + t*q_rs + h*D + d (same for K, V, O).  klen[b] = number of valid
+ * keys (NULL: all Tk).  lse [B][H][Tq] fp32 (optional).  D in {16,32,64,128}. */
+int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H, int Tq,
+                     int Tk, int D, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
+                     long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, void* stream);
+/* rows of the attention backward: P = softmax(scale*S) with key mask; dS = scale * P o (dP - sum(dP o P)) */
+int av_softmax_rows(const float* s, void* p, int pdt, long long rows, int cols, float scale, const int* klen,
+                    int rows_per_batch, int ld, void* stream);
+int av_softmax_bwd_rows(const void* p, int pdt, const float* dp, void* ds, int dsdt, long long rows, int cols,
+                        float scale, int ld, void* stream);
 
 #ifdef __cplusplus
 }

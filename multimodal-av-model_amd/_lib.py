@@ -29,6 +29,7 @@ class GemmArgs(C.Structure):
         ("cT", i32), ("cH", i32), ("cW", i32), ("cCtot", i32), ("cCin", i32), ("cCoff", i32),
         ("cKt", i32), ("cKh", i32), ("cKw", i32), ("cSh", i32), ("cSw", i32), ("cPt", i32), ("cPh", i32), ("cPw", i32),
         ("cOh", i32), ("cOw", i32),
+        ("batch_inner", i32), ("oA", ll), ("oB", ll), ("oC", ll),
     ]
 
 
@@ -45,6 +46,9 @@ SIGNATURES = {
     "av_cast": [vp, i32, vp, i32, ll, vp],
     "av_axpby": [f32, vp, i32, f32, vp, ll, vp],
     "av_mask_rows": [vp, i32, vp, ll, i32, vp],
+    "av_attention_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ll, ll, ll, ll, ll, ll, ll, ll, vp, f32, vp],
+    "av_softmax_rows": [vp, vp, i32, ll, i32, f32, vp, i32, i32, vp],
+    "av_softmax_bwd_rows": [vp, i32, vp, vp, i32, ll, i32, f32, i32, vp],
 }
 _RESTYPES = {"av_last_error": C.c_char_p}
 

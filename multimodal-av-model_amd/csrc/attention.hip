@@ -1,0 +1,339 @@
+// Fused multi-head attention forward for gfx950 (flash-style, online softmax):
+//   O = softmax(scale * Q K^T + key-padding mask) V,   LSE = log sum exp  (saved for backward)
+// replaces hf:438-463 / sdpa (wav2vec2 self-attention, 16 heads x 64) and the need_weights path of
+// nn.MultiheadAttention (torch:functional.py:6576-6606; fusion cross-attention, 4 heads x 128).
+// One workgroup = 64 query rows of one (batch, head); 4 wavefronts x 16 rows.  Q, K tiles and the transposed V
+// tile are staged in LDS; QK^T and PV run on MFMA 16x16 tiles (bf16 16x16x32 / exact-fp32 16x16x4); the row max
+// / row sum of the softmax are reduced with wavefront shuffles inside each 16-lane group (the S accumulator has
+// the key on the lane).  P goes through a per-wave LDS tile to become the A operand of PV.
+// Also here: the row kernels of the (unfused) backward: softmax rows and its gradient.
+#include "av_common.h"
+
+namespace {
+
+template <typename T> struct ACfg;
+template <> struct ACfg<float> { static constexpr int VEC = 4; };
+template <> struct ACfg<bf16_t> { static constexpr int VEC = 8; };
+
+struct AttnP {
+    const void *q, *k, *v;
+    void* o;
+    float* lse;
+    const int* klen;
+    int B, H, Tq, Tk;
+    long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    float scale;
+    int vec_ok;
+};
+
+template <typename T> __device__ __forceinline__ void zero16(T* dst) { *(uint4*)dst = make_uint4(0, 0, 0, 0); }
+
+// acc += A[16 x K] * B[16 x K]^T, both operands row-major in LDS with K contiguous
+template <typename T>
+__device__ __forceinline__ void mma_rows(f32x4& acc, const T* a, int lda, const T* b, int ldb, int K, int lane);
+template <>
+__device__ __forceinline__ void mma_rows<bf16_t>(f32x4& acc, const bf16_t* a, int lda, const bf16_t* b, int ldb, int K, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const bf16x8 av = *(const bf16x8*)(a + r * lda + k0 + 8 * g);
+        const bf16x8 bv = *(const bf16x8*)(b + r * ldb + k0 + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+    }
+}
+template <>
+__device__ __forceinline__ void mma_rows<float>(f32x4& acc, const float* a, int lda, const float* b, int ldb, int K, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const f32x4 av = *(const f32x4*)(a + r * lda + k0 + 4 * g);
+        const f32x4 bv = *(const f32x4*)(b + r * ldb + k0 + 4 * g);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[jj], acc, 0, 0, 0);
+    }
+}
+
+// stage `rows_tile` x DK elements (zero-filled outside [row_end) x [0,D)) into dst[row][ld]
+template <typename T, int D, int DK>
+__device__ __forceinline__ void stage_rows(T* dst, int ld, const T* src, long long rs, int row0, int row_end, bool vec, int tid) {
+    constexpr int VEC = ACfg<T>::VEC;
+    constexpr int CPR = DK / VEC;
+    for (int c = tid; c < 64 * CPR; c += 256) {
+        const int row = c / CPR, col = (c % CPR) * VEC;
+        const int gr = row0 + row;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gr < row_end && col < D) {
+            const T* p = src + (long long)gr * rs + col;
+            if (vec) v = *(const uint4*)p;
+            else {
+                __attribute__((aligned(16))) T tmp[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) tmp[e] = p[e];
+                v = *(const uint4*)tmp;
+            }
+        }
+        *(uint4*)(dst + row * ld + col) = v;
+    }
+}
+
+// stage V rows [row0,row0+64) transposed: dst[d][key]
+template <typename T, int D>
+__device__ __forceinline__ void stage_vt(T* dst, int ld, const T* src, long long rs, int row0, int row_end, bool vec, int tid) {
+    constexpr int VEC = ACfg<T>::VEC;
+    constexpr int CPR = D / VEC;
+    for (int c = tid; c < 64 * CPR; c += 256) {
+        const int key = c / CPR, col = (c % CPR) * VEC;
+        const int gr = row0 + key;
+        __attribute__((aligned(16))) T tmp[VEC];
+        if (gr < row_end) {
+            const T* p = src + (long long)gr * rs + col;
+            if (vec) *(uint4*)tmp = *(const uint4*)p;
+            else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) tmp[e] = p[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dst[(col + e) * ld + key] = tmp[e];
+    }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+    constexpr int DK = (D + 31) / 32 * 32;
+    constexpr int DN = D / 16;
+    constexpr int PAD = 16 / sizeof(T);
+    constexpr int LDK = DK + PAD, LDV = 64 + PAD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Qs = (T*)smem;               // [64][LDK]
+    T* Ks = Qs + 64 * LDK;          // [64][LDK]
+    T* Vt = Ks + 64 * LDK;          // [D][LDV]
+    T* Ps = Vt + D * LDV;           // [4][16][LDV]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const bool vec = p.vec_ok != 0;
+    const T* Q = (const T*)p.q + (long long)b * p.q_bs + (long long)h * D;
+    const T* K = (const T*)p.k + (long long)b * p.k_bs + (long long)h * D;
+    const T* V = (const T*)p.v + (long long)b * p.v_bs + (long long)h * D;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+
+    stage_rows<T, D, DK>(Qs, LDK, Q, p.q_rs, q0, p.Tq, vec, tid);
+
+    f32x4 O[DN];
+#pragma unroll
+    for (int n = 0; n < DN; ++n) O[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m[e] = -INFINITY; l[e] = 0.f; }
+
+    T* Pw = Ps + w * 16 * LDV;
+    const T* Qw = Qs + w * 16 * LDK;
+    for (int k0 = 0; k0 < klen; k0 += 64) {
+        stage_rows<T, D, DK>(Ks, LDK, K, p.k_rs, k0, klen, vec, tid);
+        stage_vt<T, D>(Vt, LDV, V, p.v_rs, k0, klen, vec, tid);
+        __syncthreads();
+        f32x4 S[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            S[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_rows<T>(S[j], Qw, LDK, Ks + j * 16 * LDK, LDK, DK, lane);
+        }
+        float mx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool valid = (k0 + j * 16 + r) < klen;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                S[j][e] = valid ? S[j][e] * p.scale : -INFINITY;
+                mx[e] = fmaxf(mx[e], S[j][e]);
+            }
+        }
+        float alpha[4], rs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = mx[e];
+            v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
+            v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+            const float mn = fmaxf(m[e], v);
+            alpha[e] = expf(m[e] - mn);       // first tile: exp(-inf) = 0
+            m[e] = mn;
+            rs[e] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = expf(S[j][e] - m[e]);
+                rs[e] += pv;
+                Pw[(4 * g + e) * LDV + j * 16 + r] = from_f32<T>(pv);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = rs[e];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            l[e] = l[e] * alpha[e] + v;
+        }
+#pragma unroll
+        for (int n = 0; n < DN; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) O[n][e] *= alpha[e];
+        __syncthreads();   // P visible to the whole wave (and keeps the 4 waves in step)
+#pragma unroll
+        for (int n = 0; n < DN; ++n) mma_rows<T>(O[n], Pw, LDV, Vt + n * 16 * LDV, LDV, 64, lane);
+        __syncthreads();   // K / Vt / P tiles are free again
+    }
+
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = q0 + w * 16 + 4 * g + e;
+        if (row < p.Tq) {
+            const float inv = 1.0f / l[e];
+            T* o = (T*)p.o + (long long)b * p.o_bs + (long long)row * p.o_rs + (long long)h * D;
+#pragma unroll
+            for (int n = 0; n < DN; ++n) o[n * 16 + r] = from_f32<T>(O[n][e] * inv);
+            if (r == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Tq + row] = m[e] + logf(l[e]);
+        }
+    }
+}
+
+template <typename T, int D>
+int launch_fwd(const AttnP& p, hipStream_t st) {
+    constexpr int DK = (D + 31) / 32 * 32;
+    constexpr int PAD = 16 / sizeof(T);
+    const size_t lds = sizeof(T) * (size_t)(2 * 64 * (DK + PAD) + D * (64 + PAD) + 4 * 16 * (64 + PAD));
+    auto kern = attn_fwd_kernel<T, D>;
+    static bool done = false;
+    if (!done && lds > 48 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            av_set_error("av_attention_fwd: cannot raise dynamic LDS to %zu", lds);
+            return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    dim3 grid((unsigned)((p.Tq + 63) / 64), (unsigned)p.H, (unsigned)p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+template <typename T>
+int dispatch_d(const AttnP& p, int D, hipStream_t st) {
+    switch (D) {
+        case 16: return launch_fwd<T, 16>(p, st);
+        case 32: return launch_fwd<T, 32>(p, st);
+        case 64: return launch_fwd<T, 64>(p, st);
+        case 128: return launch_fwd<T, 128>(p, st);
+        default: av_set_error("av_attention_fwd: head_dim %d not in {16,32,64,128}", D); return AV_ERR_ARG;
+    }
+}
+
+// ---- rows of the unfused backward -------------------------------------------------------------------------
+constexpr int MAXIT = 32;
+// P[row][:] = softmax(scale*S[row][:klen]) (0 beyond klen); rows are [b][h][tq]
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, void* __restrict__ pout, int pdt, long long rows,
+                                                           int cols, float scale, const int* __restrict__ klen, int rows_per_batch, int ld) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int kl = klen ? klen[row / rows_per_batch] : cols;
+    if (kl > cols) kl = cols;
+    if (kl < 1) kl = 1;
+    const long long base = row * ld;
+    float v[MAXIT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        v[it] = c < kl ? s[base + c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[it]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        v[it] = expf(v[it] - mx);
+        sum += v[it];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        if (c < cols) st_any(pout, base + c, pdt, v[it] * inv);
+    }
+}
+
+// dS = scale * P o (dP - sum(dP o P))
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const void* __restrict__ pm, int pdt, const float* __restrict__ dp,
+                                                               void* __restrict__ ds, int dsdt, long long rows, int cols, float scale, int ld) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long base = row * ld;
+    float pv[MAXIT], dv[MAXIT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        pv[it] = c < cols ? ld_any(pm, base + c, pdt) : 0.f;
+        dv[it] = c < cols ? dp[base + c] : 0.f;
+        s += pv[it] * dv[it];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = lane + 64 * it;
+        if (c < cols) st_any(ds, base + c, dsdt, scale * pv[it] * (dv[it] - s));
+    }
+}
+
+}  // namespace
+
+extern "C" int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H, int Tq,
+                                int Tk, int D, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
+                                long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, void* stream) {
+    AV_CHECK(q && k && v && o, "av_attention_fwd: null pointer");
+    AV_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0, "av_attention_fwd: bad shape B=%d H=%d Tq=%d Tk=%d", B, H, Tq, Tk);
+    AV_CHECK(dtype == AV_F32 || dtype == AV_BF16, "av_attention_fwd: bad dtype %d", dtype);
+    AttnP p;
+    p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.klen = klen;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
+    p.scale = scale;
+    const long long es = dtype == AV_F32 ? 4 : 2;
+    auto al = [&](const void* ptr, long long bs, long long rs) {
+        return ((uintptr_t)ptr % 16 == 0) && ((bs * es) % 16 == 0) && ((rs * es) % 16 == 0) && ((D * es) % 16 == 0);
+    };
+    p.vec_ok = al(q, q_bs, q_rs) && al(k, k_bs, k_rs) && al(v, v_bs, v_rs);
+    return dtype == AV_F32 ? dispatch_d<float>(p, D, (hipStream_t)stream) : dispatch_d<bf16_t>(p, D, (hipStream_t)stream);
+}
+
+extern "C" int av_softmax_rows(const float* s, void* p, int pdt, long long rows, int cols, float scale, const int* klen,
+                               int rows_per_batch, int ld, void* stream) {
+    AV_CHECK(s && p, "av_softmax_rows: null pointer");
+    AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_softmax_rows: cols=%d out of range (1..%d)", cols, 64 * MAXIT);
+    AV_CHECK(rows_per_batch > 0, "av_softmax_rows: rows_per_batch=%d", rows_per_batch);
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, p, pdt, rows, cols,
+                       scale, klen, rows_per_batch, ld);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_softmax_bwd_rows(const void* p, int pdt, const float* dp, void* ds, int dsdt, long long rows, int cols, float scale,
+                                   int ld, void* stream) {
+    AV_CHECK(p && dp && ds, "av_softmax_bwd_rows: null pointer");
+    AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_softmax_bwd_rows: cols=%d out of range", cols);
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, pdt, dp, ds,
+                       dsdt, rows, cols, scale, ld);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

@@ -237,8 +237,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const av_gemm_args p, const in
     const int mb = blockIdx.x / nbN, nb = blockIdx.x % nbN;
     const int m0 = mb * BM, n0 = nb * BN;
     const int z = blockIdx.z;
-    const T* A = (const T*)p.A + (long long)z * p.sA;
-    const T* B = (const T*)p.B + (long long)z * p.sB;
+    const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
+    const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
+    const T* A = (const T*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
+    const T* B = (const T*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
 
     RowInfo<T, BM> ri;
     init_rows<T, BM, AMODE>(ri, p, m0, p.M, tid);
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const av_gemm_args p, const in
 
     // ---------------- epilogue ----------------
     const int r = lane & 15, g = lane >> 4;
-    const long long cbase = (long long)z * p.sC;
-    const float* R = p.R ? p.R + (long long)z * p.sR : nullptr;
+    const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
+    const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
     float csum[WN_T], csq[WN_T];
 #pragma unroll
     for (int j = 0; j < WN_T; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const av_gemm_args p, const in
     for (int j = 0; j < WN_T; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 16 + r;
         const bool nok = n < p.N;
-        const float bias = (p.bias && nok) ? p.bias[(long long)z * p.sBias + n] : 0.f;
+        const float bias = (p.bias && nok) ? p.bias[(long long)zi * p.sBias + n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -360,6 +362,9 @@ bool vec_ok(const void* base, long long ld, long long stride) {
     const long long es = sizeof(T);
     return ((uintptr_t)base % 16 == 0) && ((ld * es) % 16 == 0) && ((stride * es) % 16 == 0);
 }
+template <typename T> bool vec_ok2(const void* base, long long ld, long long s1, long long s2) {
+    return vec_ok<T>(base, ld, s1) && ((s2 * (long long)sizeof(T)) % 16 == 0);
+}
 
 }  // namespace
 
@@ -388,10 +393,10 @@ extern "C" int av_gemm(const av_gemm_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool wide = p.N > 64;
     if (p.in_dtype == AV_F32) {
-        const bool av = vec_ok<float>(p.A, p.lda, p.sA), bv = vec_ok<float>(p.B, p.ldb, p.sB);
+        const bool av = vec_ok2<float>(p.A, p.lda, p.sA, p.oA), bv = vec_ok2<float>(p.B, p.ldb, p.sB, p.oB);
         return wide ? dispatch_modes<float, 128>(p, st, av, bv) : dispatch_modes<float, 64>(p, st, av, bv);
     } else {
-        const bool av = vec_ok<bf16_t>(p.A, p.lda, p.sA), bv = vec_ok<bf16_t>(p.B, p.ldb, p.sB);
+        const bool av = vec_ok2<bf16_t>(p.A, p.lda, p.sA, p.oA), bv = vec_ok2<bf16_t>(p.B, p.ldb, p.sB, p.oB);
         return wide ? dispatch_modes<bf16_t, 128>(p, st, av, bv) : dispatch_modes<bf16_t, 64>(p, st, av, bv);
     }
 }

@@ -44,7 +44,8 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
          a_mode: int = L.A_ROWMAJOR, b_mode: int = L.B_NK, bias: Optional[Tensor] = None, act: int = L.ACT_NONE,
          R: Optional[Tensor] = None, ldr: int = 0, aux: Optional[Tensor] = None, C2: Optional[Tensor] = None,
          stats: Optional[Tensor] = None, alpha: float = 1.0, batch: int = 1, sA: int = 0, sB: int = 0, sC: int = 0,
-         sR: int = 0, sBias: int = 0, conv: Optional[dict] = None, a_off: int = 0, b_off: int = 0, c_off: int = 0) -> Tensor:
+         sR: int = 0, sBias: int = 0, conv: Optional[dict] = None, a_off: int = 0, b_off: int = 0, c_off: int = 0,
+         batch_inner: int = 0, oA: int = 0, oB: int = 0, oC: int = 0) -> Tensor:
     """Raw av_gemm call.  Offsets are in elements."""
     _req(A, "gemm A"); _req(B, "gemm B"); _req(C_, "gemm C")
     if A.dtype != B.dtype:
@@ -59,6 +60,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.lda, a.ldb, a.ldc, a.ldr = lda, ldb, ldc, (ldr or ldc)
     a.sA, a.sB, a.sC, a.sR, a.sBias = sA, sB, sC, sR, sBias
+    a.batch_inner, a.oA, a.oB, a.oC = batch_inner, oA, oB, oC
     a.a_mode, a.b_mode = a_mode, b_mode
     a.in_dtype, a.out_dtype = dt(A), dt(C_)
     a.aux_dtype = dt(aux) if aux is not None else 0
@@ -189,3 +191,57 @@ def mask_rows_(x: Tensor, keep_u8: Tensor) -> Tensor:
     cols = x.shape[-1]
     L.check(L.lib().av_mask_rows(ptr(x), dt(x), ptr(keep_u8), x.numel() // cols, cols, stream()), "av_mask_rows")
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# attention.  q/k/v/o are [B, T, H, D] views (last dim contiguous, head stride == D), e.g. slices of a packed
+# [B, T, 3, H, D] projection buffer — no copies are made.
+# ---------------------------------------------------------------------------------------------------------------
+def _chk_view(t: Tensor, name: str):
+    if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) != t.shape[3]:
+        raise ValueError(f"{name}: expected a [B,T,H,D] view with contiguous D and head stride D, got {tuple(t.shape)} / {t.stride()}")
+
+
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, klen: Optional[Tensor], scale: float, need_lse: bool = True):
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk_view(t, n)
+    B, Tq, H, D = q.shape
+    Tk = k.shape[1]
+    o = torch.empty((B, Tq, H, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if need_lse else None
+    L.check(L.lib().av_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), dt(q), B, H, Tq, Tk, D,
+                                     q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                     o.stride(0), o.stride(1), ptr(klen), scale, stream()), "av_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: Tensor, dv: Tensor, klen: Optional[Tensor],
+                  scale: float) -> None:
+    """Backward of attention_fwd from batched MFMA GEMMs + row kernels (P is re-materialised, T x T is small here):
+    P = softmax(scale QK^T); dV = P^T dO; dP = dO V^T; dS = scale P o (dP - rowsum(dP o P)); dQ = dS K; dK = dS^T Q.
+    dq/dk/dv are [B,T,H,D] output views (written in place)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (do, "do"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk_view(t, n)
+    B, Tq, H, D = q.shape
+    Tk = k.shape[1]
+    ld = (Tk + 7) // 8 * 8
+    dev = q.device
+    S = torch.empty((B, H, Tq, ld), dtype=torch.float32, device=dev)
+    bh = dict(batch=B * H, batch_inner=H)
+    gemm(q, k, S, M=Tq, N=Tk, K=D, lda=q.stride(1), ldb=k.stride(1), ldc=ld, sA=D, oA=q.stride(0), sB=D, oB=k.stride(0),
+         sC=Tq * ld, oC=H * Tq * ld, **bh)
+    P = torch.empty((B, H, Tq, ld), dtype=q.dtype, device=dev)
+    L.check(L.lib().av_softmax_rows(ptr(S), ptr(P), dt(P), B * H * Tq, Tk, scale, ptr(klen), H * Tq, ld, stream()), "av_softmax_rows")
+    # dV[key, d] = sum_q P[q, key] dO[q, d]
+    gemm(P, do, dv, M=Tk, N=D, K=Tq, lda=ld, ldb=do.stride(1), ldc=dv.stride(1), a_mode=L.A_TRANS, b_mode=L.B_KN,
+         sA=Tq * ld, oA=H * Tq * ld, sB=D, oB=do.stride(0), sC=D, oC=dv.stride(0), **bh)
+    # dP = dO V^T  (into S)
+    gemm(do, v, S, M=Tq, N=Tk, K=D, lda=do.stride(1), ldb=v.stride(1), ldc=ld, sA=D, oA=do.stride(0), sB=D, oB=v.stride(0),
+         sC=Tq * ld, oC=H * Tq * ld, **bh)
+    dS = torch.empty((B, H, Tq, ld), dtype=q.dtype, device=dev)
+    L.check(L.lib().av_softmax_bwd_rows(ptr(P), dt(P), ptr(S), ptr(dS), dt(dS), B * H * Tq, Tk, scale, ld, stream()), "av_softmax_bwd_rows")
+    # dQ = dS K ; dK = dS^T Q
+    gemm(dS, k, dq, M=Tq, N=D, K=Tk, lda=ld, ldb=k.stride(1), ldc=dq.stride(1), b_mode=L.B_KN, sA=Tq * ld, oA=H * Tq * ld,
+         sB=D, oB=k.stride(0), sC=D, oC=dq.stride(0), **bh)
+    gemm(dS, q, dk, M=Tk, N=D, K=Tq, lda=ld, ldb=q.stride(1), ldc=dk.stride(1), a_mode=L.A_TRANS, b_mode=L.B_KN,
+         sA=Tq * ld, oA=H * Tq * ld, sB=D, oB=q.stride(0), sC=D, oC=dk.stride(0), **bh)

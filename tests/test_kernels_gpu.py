@@ -177,3 +177,39 @@ def test_log_softmax_colsum_cast():
     keep = (torch.rand(1300, device="cuda") > 0.3).to(torch.uint8)
     m = ops.mask_rows_(big.clone(), keep)
     torch.testing.assert_close(m, big * keep[:, None].float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Tq,Tk,D,masked", [(2, 4, 49, 49, 16, False), (3, 16, 199, 199, 64, True), (2, 4, 100, 100, 128, False),
+                                                (2, 4, 25, 25, 128, False), (1, 2, 300, 300, 64, True), (2, 3, 70, 130, 32, True)])
+def test_attention_fwd_bwd(dtype, B, H, Tq, Tk, D, masked):
+    packed = Tq == Tk
+    if packed:
+        qkv = _rand(B, Tq, 3, H, D, dtype=dtype)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    else:
+        q = _rand(B, Tq, H, D, dtype=dtype); kv = _rand(B, Tk, 2, H, D, dtype=dtype)
+        k, v = kv[:, :, 0], kv[:, :, 1]
+    klen = None
+    if masked:
+        klen = torch.tensor([Tk, max(1, Tk // 2), max(1, Tk - 3)][:B], device="cuda", dtype=torch.int32)
+    scale = D ** -0.5
+    o, lse = ops.attention_fwd(q, k, v, klen, scale)
+    qr, kr, vr = (t.float().permute(0, 2, 1, 3).detach().clone().requires_grad_(True) for t in (q, k, v))
+    s = (qr.double() @ kr.double().transpose(2, 3)) * scale
+    if masked:
+        keep = torch.arange(Tk, device="cuda")[None, :] < klen[:, None]
+        s = s.masked_fill(~keep[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vr.double()).float()
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(o.float().permute(0, 2, 1, 3), ref, **tol)
+    torch.testing.assert_close(lse, torch.logsumexp(s, -1).float(), rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=1e-3 if dtype == torch.float32 else 5e-2)
+    do = _rand(B, Tq, H, D, dtype=dtype)
+    ref.backward(do.float().permute(0, 2, 1, 3))
+    dq = torch.empty(B, Tq, H, D, device="cuda", dtype=dtype); dk = torch.empty(B, Tk, H, D, device="cuda", dtype=dtype)
+    dv = torch.empty(B, Tk, H, D, device="cuda", dtype=dtype)
+    ops.attention_bwd(q, k, v, do, dq, dk, dv, klen, scale)
+    btol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(dq.float().permute(0, 2, 1, 3), qr.grad, **btol)
+    torch.testing.assert_close(dk.float().permute(0, 2, 1, 3), kr.grad, **btol)
+    torch.testing.assert_close(dv.float().permute(0, 2, 1, 3), vr.grad, **btol)
