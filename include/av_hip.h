@@ -105,6 +105,11 @@ int av_softmax_rows(const float* s, void* p, int pdt, long long rows, int cols, 
 int av_softmax_bwd_rows(const void* p, int pdt, const float* dp, void* ds, int dsdt, long long rows, int cols,
                         float scale, int ld, void* stream);
 
+/* ---- wav2vec2 feature-encoder layer 0, fused Conv1d(1->C,k,stride)+bias -> LayerNorm(C) -> GELU (hf:291-299).
+ * wav [B][T_in] fp32 -> out [B][L_out][C] channel-last in out_dtype; w [C][k] fp32. */
+int av_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, void* out,
+                     int out_dtype, int B, int T_in, int L_out, int C, int k, int stride, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,7 @@ SIGNATURES = {
     "av_mask_rows": [vp, i32, vp, ll, i32, vp],
     "av_attention_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ll, ll, ll, ll, ll, ll, ll, ll, vp, f32, vp],
     "av_softmax_rows": [vp, vp, i32, ll, i32, f32, vp, i32, i32, vp],
+    "av_conv0_ln_gelu": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "av_softmax_bwd_rows": [vp, i32, vp, vp, i32, ll, i32, f32, i32, vp],
 }
 _RESTYPES = {"av_last_error": C.c_char_p}

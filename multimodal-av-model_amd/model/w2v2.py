@@ -1,0 +1,358 @@
+"""wav2vec2 (stable-layer-norm / XLSR architecture) forward + backward on the HIP kernels.
+
+Mirrors the arithmetic of HuggingFace ``Wav2Vec2Model`` as the reference uses it (model/encoder.py:80-100;
+hf:275-299 feature encoder, hf:422-434 projection, hf:326-379 positional conv, hf:611-654 + 729-802 pre-LN
+encoder, hf:997-1036 length law) with the parameter names of the HF checkpoint, so ``main.py:26-31``'s
+name-based freeze policy and ``load_state_dict`` keep working.  Config-driven.
+
+Layout in HBM: activations are channel-last ``[B, T, C]``; the residual stream is fp32, GEMM operands are in the
+compute dtype (fp32 parity mode / bf16 perf mode); Q,K,V live in one packed ``[B, T, 3, heads, hd]`` buffer.
+Backward is hand-written (no autograd graph inside): it stops at the lowest layer that owns a trainable
+parameter, so nothing below encoder layer 6 is ever differentiated.
+"""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+from ..precision import compute_dtype
+from ..utils import init as _init
+
+Tensor = torch.Tensor
+
+
+def param_shapes(cfg: dict) -> Dict[str, tuple]:
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    shapes: Dict[str, tuple] = {"masked_spec_embed": (H,)}
+    cin = 1
+    for i, (c, k) in enumerate(zip(cfg["conv_dim"], cfg["conv_kernel"])):
+        p = f"feature_extractor.conv_layers.{i}"
+        shapes[p + ".conv.weight"] = (c, cin, k); shapes[p + ".conv.bias"] = (c,)
+        shapes[p + ".layer_norm.weight"] = (c,); shapes[p + ".layer_norm.bias"] = (c,)
+        cin = c
+    shapes["feature_projection.layer_norm.weight"] = (cin,); shapes["feature_projection.layer_norm.bias"] = (cin,)
+    shapes["feature_projection.projection.weight"] = (H, cin); shapes["feature_projection.projection.bias"] = (H,)
+    kp, gp = cfg["num_conv_pos_embeddings"], cfg["num_conv_pos_embedding_groups"]
+    shapes["encoder.pos_conv_embed.conv.bias"] = (H,)
+    shapes["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (1, 1, kp)
+    shapes["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = (H, H // gp, kp)
+    shapes["encoder.layer_norm.weight"] = (H,); shapes["encoder.layer_norm.bias"] = (H,)
+    for li in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layers.{li}"
+        for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            shapes[f"{p}.attention.{nm}.weight"] = (H, H); shapes[f"{p}.attention.{nm}.bias"] = (H,)
+        shapes[p + ".layer_norm.weight"] = (H,); shapes[p + ".layer_norm.bias"] = (H,)
+        shapes[p + ".feed_forward.intermediate_dense.weight"] = (I, H); shapes[p + ".feed_forward.intermediate_dense.bias"] = (I,)
+        shapes[p + ".feed_forward.output_dense.weight"] = (H, I); shapes[p + ".feed_forward.output_dense.bias"] = (H,)
+        shapes[p + ".final_layer_norm.weight"] = (H,); shapes[p + ".final_layer_norm.bias"] = (H,)
+    return shapes
+
+
+def build_param_tree(root: nn.Module, shapes: Dict[str, tuple]) -> None:
+    """Nested plain nn.Modules whose dotted parameter names equal the HF checkpoint keys."""
+    for name, shape in shapes.items():
+        parts = name.split(".")
+        m = root
+        for p in parts[:-1]:
+            if p not in m._modules:
+                m.add_module(p, nn.Module())
+            m = m._modules[p]
+        m.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape, dtype=torch.float32)))
+
+
+def conv_out_lengths(cfg: dict, n):
+    """hf:997-1015  L <- floor((L-k)/s)+1 (works on ints and integer tensors)."""
+    for k, s in zip(cfg["conv_kernel"], cfg["conv_stride"]):
+        n = (n - k) // s + 1
+    return n
+
+
+class _Cache:
+    """Compute-dtype copies / re-layouts of parameters, refreshed when the parameter is updated in place."""
+
+    def __init__(self):
+        self.d = {}
+
+    def get(self, key, params: List[Tensor], dtype, fn):
+        ver = tuple((p._version, p.data_ptr()) for p in params) + (dtype,)
+        hit = self.d.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                hit = (ver, fn())
+            self.d[key] = hit
+        return hit[1]
+
+
+class Wav2Vec2ModelHIP(nn.Module):
+    """Drop-in for the ``transformers.Wav2Vec2Model`` instance the reference stores in ``AudioEncoder.model``."""
+
+    def __init__(self, cfg: dict):
+        super().__init__()
+        self.cfg = dict(cfg)
+        self.config = SimpleNamespace(**cfg, output_hidden_states=True)
+        build_param_tree(self, param_shapes(cfg))
+        self._cache = _Cache()
+        self._names = [n for n, _ in self.named_parameters()]
+
+    # ---- parameter access ------------------------------------------------------------------------------------
+    def P(self, name: str) -> Tensor:
+        m = self
+        for p in name.split("."):
+            m = m._modules[p] if p in m._modules else m._parameters[p]
+        return m
+
+    def c(self, name: str, dtype) -> Tensor:
+        """Parameter in the compute dtype (cached)."""
+        p = self.P(name)
+        if dtype == torch.float32:
+            return p.data
+        return self._cache.get(("c", name), [p], dtype, lambda: ops.cast(p.data, dtype))
+
+    def qkv_w(self, li: int, dtype):
+        ps = [self.P(f"encoder.layers.{li}.attention.{n}_proj.weight") for n in ("q", "k", "v")]
+        return self._cache.get(("qkvw", li), ps, dtype, lambda: ops.cast(torch.cat([p.data for p in ps], 0).contiguous(), dtype))
+
+    def qkv_b(self, li: int):
+        ps = [self.P(f"encoder.layers.{li}.attention.{n}_proj.bias") for n in ("q", "k", "v")]
+        return self._cache.get(("qkvb", li), ps, torch.float32, lambda: torch.cat([p.data for p in ps], 0).contiguous())
+
+    def conv_w(self, i: int, dtype):
+        """Conv1d weight [C_out, C_in, k] -> [C_out, k*C_in] (tap-major K, matching the channel-last im2col rows)."""
+        p = self.P(f"feature_extractor.conv_layers.{i}.conv.weight")
+        return self._cache.get(("convw", i), [p], dtype,
+                               lambda: ops.cast(p.data.permute(0, 2, 1).contiguous().view(p.shape[0], -1), dtype))
+
+    def pos_w(self, dtype):
+        """weight_norm(dim=2) folded once (frozen): w = v*g/||v||_(0,1); layout [group][c_out][tap][c_in] (hf:355)."""
+        g = self.P("encoder.pos_conv_embed.conv.parametrizations.weight.original0")
+        v = self.P("encoder.pos_conv_embed.conv.parametrizations.weight.original1")
+        G = self.cfg["num_conv_pos_embedding_groups"]
+
+        def make():
+            w = v.data * (g.data / v.data.norm(2, dim=(0, 1), keepdim=True))          # [H, H/G, k]
+            Hd, Cg, k = w.shape
+            w = w.view(G, Hd // G, Cg, k).permute(0, 1, 3, 2).contiguous()            # [G, co, k, ci]
+            return ops.cast(w.view(G, Hd // G, k * Cg), dtype)
+        return self._cache.get(("posw",), [g, v], dtype, make)
+
+    # ---- which layers need a backward -----------------------------------------------------------------------
+    def trainable_layers(self) -> List[bool]:
+        return [any(p.requires_grad for p in self._modules["encoder"]._modules["layers"]._modules[str(li)].parameters())
+                for li in range(self.cfg["num_hidden_layers"])]
+
+    def check_freeze_policy(self):
+        bad = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("encoder.layers.")]
+        if bad:
+            raise NotImplementedError(
+                "the HIP backward covers encoder.layers.* (the reference trains layers 6-9 only, main.py:26-31); "
+                f"freeze these parameters: {bad[:4]}{'...' if len(bad) > 4 else ''}")
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def features(self, wav: Tensor, dtype) -> Tensor:
+        """K1: 7 x (conv + LayerNorm + GELU) -> [B, T_enc, C] in the compute dtype (frozen, nothing saved)."""
+        cfg = self.cfg
+        B, T_in = wav.shape
+        ks, ss, cs = cfg["conv_kernel"], cfg["conv_stride"], cfg["conv_dim"]
+        L0 = (T_in - ks[0]) // ss[0] + 1
+        p = "feature_extractor.conv_layers.0."
+        h = torch.empty((B, L0, cs[0]), dtype=dtype, device=wav.device)
+        L.check(L.lib().av_conv0_ln_gelu(ops.ptr(wav), ops.ptr(self.P(p + "conv.weight").data), ops.ptr(self.P(p + "conv.bias").data),
+                                         ops.ptr(self.P(p + "layer_norm.weight").data), ops.ptr(self.P(p + "layer_norm.bias").data),
+                                         ops.ptr(h), ops.dt(h), B, T_in, L0, cs[0], ks[0], ss[0], 1e-5, ops.stream()), "av_conv0_ln_gelu")
+        Lin, cin = L0, cs[0]
+        for i in range(1, len(ks)):
+            p = f"feature_extractor.conv_layers.{i}."
+            Lout = (Lin - ks[i]) // ss[i] + 1
+            y = torch.empty((B, Lout, cs[i]), dtype=dtype, device=wav.device)
+            # strided GEMM: im2col row t of a channel-last signal is the contiguous slice x[s*t : s*t+k, :]
+            ops.gemm(h, self.conv_w(i, dtype), y, M=Lout, N=cs[i], K=ks[i] * cin, lda=ss[i] * cin, ldb=ks[i] * cin, ldc=cs[i],
+                     bias=self.P(p + "conv.bias").data, batch=B, sA=Lin * cin, sC=Lout * cs[i])
+            h = ops.layernorm_fwd(y, self.P(p + "layer_norm.weight").data, self.P(p + "layer_norm.bias").data, out_dtype=dtype,
+                                  eps=1e-5, act=L.ACT_GELU)
+            Lin, cin = Lout, cs[i]
+        return h
+
+    def encode(self, wav: Tensor, attention_mask: Optional[Tensor], save: bool):
+        """Returns (last fp32, mid fp32, ctx).  ctx holds what backward needs when ``save``."""
+        cfg = self.cfg
+        dtype = compute_dtype()
+        dev = wav.device
+        eps = cfg["layer_norm_eps"]
+        Hd, nh = cfg["hidden_size"], cfg["num_attention_heads"]
+        hd = Hd // nh
+        nl = cfg["num_hidden_layers"]
+        wav = wav.contiguous().float()
+        feats = self.features(wav, dtype)
+        B, T, C = feats.shape
+        klen = keep = None
+        if attention_mask is not None:
+            n = conv_out_lengths(cfg, attention_mask.long().sum(-1))
+            klen = n.clamp(min=1, max=T).to(torch.int32)
+            keep = (torch.arange(T, device=dev)[None, :] < n[:, None]).to(torch.uint8).contiguous()
+        x = ops.layernorm_fwd(feats, self.P("feature_projection.layer_norm.weight").data,
+                              self.P("feature_projection.layer_norm.bias").data, out_dtype=dtype, eps=eps)
+        h = ops.linear(x, self.c("feature_projection.projection.weight", dtype), self.P("feature_projection.projection.bias").data,
+                       out_dtype=torch.float32)
+        if keep is not None:
+            ops.mask_rows_(h, keep)                                                      # hf:752-755
+        # positional conv (grouped, k taps) as an implicit-im2col GEMM per group, + bias, GELU, + residual
+        kp, G = cfg["num_conv_pos_embeddings"], cfg["num_conv_pos_embedding_groups"]
+        Cg = Hd // G
+        hT = ops.cast(h, dtype)
+        hs0 = torch.empty_like(h)
+        conv = dict(cT=1, cH=T, cW=1, cCtot=Hd, cCin=Cg, cCoff=0, cKt=1, cKh=kp, cKw=1, cSh=1, cSw=1, cPt=0, cPh=kp // 2, cPw=0,
+                    cOh=T, cOw=1)
+        ops.gemm(hT, self.pos_w(dtype), hs0, M=B * T, N=Cg, K=kp * Cg, lda=0, ldb=kp * Cg, ldc=Hd, a_mode=L.A_CONV2D, conv=conv,
+                 bias=self.P("encoder.pos_conv_embed.conv.bias").data, act=L.ACT_GELU, R=h, ldr=Hd, batch=G, sA=Cg, sB=Cg * kp * Cg,
+                 sC=Cg, sR=Cg, sBias=Cg)
+        h = hs0
+        train = self.trainable_layers() if save else [False] * nl
+        first = train.index(True) if any(train) else nl
+        mid = torch.zeros_like(h) if nl >= 10 else None
+        saved = [None] * nl
+        scale = hd ** -0.5
+        for li in range(nl):
+            if mid is not None and 6 <= li <= 9:
+                ops.axpby(0.25, h, 1.0, mid)                                             # model/encoder.py:97-99
+            p = f"encoder.layers.{li}."
+            keep_ctx = save and li >= first
+            x1, mu1, rs1 = ops.layernorm_fwd(h, self.P(p + "layer_norm.weight").data, self.P(p + "layer_norm.bias").data,
+                                             out_dtype=dtype, eps=eps, save_stats=True)
+            qkv = ops.linear(x1, self.qkv_w(li, dtype), self.qkv_b(li), out_dtype=dtype).view(B, T, 3, nh, hd)
+            ao, _ = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], klen, scale, need_lse=False)
+            h2 = ops.linear(ao.view(B, T, Hd), self.c(p + "attention.out_proj.weight", dtype), self.P(p + "attention.out_proj.bias").data,
+                            out_dtype=torch.float32, R=h)
+            x2, mu2, rs2 = ops.layernorm_fwd(h2, self.P(p + "final_layer_norm.weight").data, self.P(p + "final_layer_norm.bias").data,
+                                             out_dtype=dtype, eps=eps, save_stats=True)
+            u = torch.empty((B, T, cfg["intermediate_size"]), dtype=dtype, device=dev) if keep_ctx else None
+            g = ops.linear(x2, self.c(p + "feed_forward.intermediate_dense.weight", dtype),
+                           self.P(p + "feed_forward.intermediate_dense.bias").data, out_dtype=dtype, act=L.ACT_GELU, C2=u)
+            h3 = ops.linear(g, self.c(p + "feed_forward.output_dense.weight", dtype), self.P(p + "feed_forward.output_dense.bias").data,
+                            out_dtype=torch.float32, R=h2)
+            if keep_ctx:
+                tr = train[li]
+                saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, h2=h2, mu2=mu2, rs2=rs2, u=u,
+                                 x1=x1 if tr else None, x2=x2 if tr else None, g=g if tr else None)
+            h = h3
+        last, muf, rsf = ops.layernorm_fwd(h, self.P("encoder.layer_norm.weight").data, self.P("encoder.layer_norm.bias").data,
+                                           out_dtype=torch.float32, eps=eps, save_stats=True)
+        if mid is None:
+            mid = torch.zeros_like(last)
+        ctx = None
+        if save and first < nl:
+            ctx = dict(saved=saved, hL=h, muf=muf, rsf=rsf, klen=klen, first=first, train=train, B=B, T=T, dtype=dtype)
+        return last, mid, ctx
+
+    # ---- backward --------------------------------------------------------------------------------------------
+    def backward(self, ctx: dict, dlast: Optional[Tensor], dmid: Optional[Tensor]) -> Dict[str, Tensor]:
+        """Gradients of the trainable encoder-layer parameters given d(last_hidden_state) and d(mid)."""
+        cfg = self.cfg
+        dtype = ctx["dtype"]
+        B, T = ctx["B"], ctx["T"]
+        Hd, nh, I = cfg["hidden_size"], cfg["num_attention_heads"], cfg["intermediate_size"]
+        hd = Hd // nh
+        nl = cfg["num_hidden_layers"]
+        scale = hd ** -0.5
+        grads: Dict[str, Tensor] = {}
+        dev = ctx["hL"].device
+        if dlast is not None:
+            dh = ops.layernorm_bwd(ctx["hL"], dlast.contiguous().float(), self.P("encoder.layer_norm.weight").data, ctx["muf"], ctx["rsf"])
+        else:
+            dh = torch.zeros((B, T, Hd), dtype=torch.float32, device=dev)
+        dmid_c = dmid.contiguous().float() if dmid is not None else None
+        for li in range(nl - 1, ctx["first"] - 1, -1):
+            if dmid_c is not None and 6 <= li + 1 <= 9 and li + 1 < nl:
+                ops.axpby(0.25, dmid_c, 1.0, dh)
+            s = ctx["saved"][li]
+            tr = ctx["train"][li]
+            p = f"encoder.layers.{li}."
+            M = B * T
+            dh3 = dh
+            dh3_t = ops.cast(dh3, dtype)
+            W2 = self.c(p + "feed_forward.output_dense.weight", dtype)            # [Hd, I]
+            du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I))
+            if tr:
+                grads[p + "feed_forward.output_dense.weight"] = ops.matmul_tn(dh3_t.view(M, Hd), s["g"].view(M, I))
+                grads[p + "feed_forward.output_dense.bias"] = ops.colsum(dh3.view(M, Hd))
+            W1 = self.c(p + "feed_forward.intermediate_dense.weight", dtype)      # [I, Hd]
+            dx2 = ops.matmul_nn(du, W1, out_dtype=dtype)
+            if tr:
+                grads[p + "feed_forward.intermediate_dense.weight"] = ops.matmul_tn(du, s["x2"].view(M, Hd))
+                grads[p + "feed_forward.intermediate_dense.bias"] = ops.colsum(du)
+            r = ops.layernorm_bwd(s["h2"], dx2.view(B, T, Hd), self.P(p + "final_layer_norm.weight").data, s["mu2"], s["rs2"], dres=dh3,
+                                  want_param_grads=tr)
+            if tr:
+                dh2, grads[p + "final_layer_norm.weight"], grads[p + "final_layer_norm.bias"] = r
+            else:
+                dh2 = r
+            dh2_t = ops.cast(dh2, dtype)
+            Wo = self.c(p + "attention.out_proj.weight", dtype)
+            dao = ops.matmul_nn(dh2_t.view(M, Hd), Wo, out_dtype=dtype).view(B, T, nh, hd)
+            if tr:
+                grads[p + "attention.out_proj.weight"] = ops.matmul_tn(dh2_t.view(M, Hd), s["ao"].view(M, Hd))
+                grads[p + "attention.out_proj.bias"] = ops.colsum(dh2.view(M, Hd))
+            qkv = s["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dao, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx["klen"], scale)
+            dx1 = ops.matmul_nn(dqkv.view(M, 3 * Hd), self.qkv_w(li, dtype), out_dtype=dtype)
+            if tr:
+                dW = ops.matmul_tn(dqkv.view(M, 3 * Hd), s["x1"].view(M, Hd))
+                db = ops.colsum(dqkv.view(M, 3 * Hd))
+                for j, n in enumerate(("q", "k", "v")):
+                    grads[p + f"attention.{n}_proj.weight"] = dW[j * Hd:(j + 1) * Hd]
+                    grads[p + f"attention.{n}_proj.bias"] = db[j * Hd:(j + 1) * Hd]
+            r = ops.layernorm_bwd(s["h"], dx1.view(B, T, Hd), self.P(p + "layer_norm.weight").data, s["mu1"], s["rs1"], dres=dh2,
+                                  want_param_grads=tr)
+            if tr:
+                dh, grads[p + "layer_norm.weight"], grads[p + "layer_norm.bias"] = r
+            else:
+                dh = r
+            ctx["saved"][li] = None        # free as we go
+        return grads
+
+
+class _EncodeFn(torch.autograd.Function):
+    """Autograd boundary: (wav, mask, trainable params...) -> (last, mid)."""
+
+    @staticmethod
+    def forward(fctx, model: Wav2Vec2ModelHIP, wav, attention_mask, names, *params):
+        last, mid, ctx = model.encode(wav, attention_mask, save=True)
+        fctx.model, fctx.ctx, fctx.names = model, ctx, names
+        return last, mid
+
+    @staticmethod
+    def backward(fctx, dlast, dmid):
+        if fctx.ctx is None:
+            return (None, None, None, None) + tuple(None for _ in fctx.names)
+        g = fctx.model.backward(fctx.ctx, dlast, dmid)
+        fctx.ctx = None
+        return (None, None, None, None) + tuple(g.get(n) for n in fctx.names)
+
+
+def w2v2_apply(model: Wav2Vec2ModelHIP, wav: Tensor, attention_mask: Optional[Tensor]):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+        model.check_freeze_policy()
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        params = [model.P(n) for n in names]
+        return _EncodeFn.apply(model, wav, attention_mask, names, *params)
+    with torch.no_grad():
+        last, mid, _ = model.encode(wav, attention_mask, save=False)
+    return last, mid
+
+
+def load_local_config(path: str) -> dict:
+    """``config.json`` of a LOCAL HF wav2vec2 directory (no network is ever touched)."""
+    with open(os.path.join(path, "config.json"), "r", encoding="utf-8") as f:
+        c = json.load(f)
+    if c.get("feat_extract_norm", "layer") != "layer" or not c.get("do_stable_layer_norm", True):
+        raise NotImplementedError("only the stable-layer-norm / feat_extract_norm='layer' (XLSR) architecture is built")
+    keys = ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "conv_dim", "conv_kernel", "conv_stride",
+            "num_conv_pos_embeddings", "num_conv_pos_embedding_groups", "layer_norm_eps")
+    return {k: (tuple(c[k]) if isinstance(c[k], list) else c[k]) for k in keys}

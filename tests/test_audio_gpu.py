@@ -1,0 +1,77 @@
+"""GPU parity of the HIP wav2vec2 path against the CPU oracle (fp32 mode: 1e-3 gate; bf16: reported tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfg_name, B, seconds, ragged, precision):
+    init = pkg("utils.init"); synth = pkg("dataset.synthetic"); enc = pkg("model.encoder"); prec = pkg("precision")
+    from oracle import av_oracle as O
+    cfg = getattr(init, cfg_name)
+    prec.set_precision(precision)
+    batch = synth.make_batch(B, seconds, seed=42, ragged=ragged)
+    sd = init.w2v2_state_dict(cfg)
+    ae = enc.AudioEncoder(dict(cfg), freeze=True).cuda()
+    ae.load_state_dict(sd)
+    return cfg, batch, sd, ae, O
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 0.15)])
+@pytest.mark.parametrize("cfg_name,ragged", [("W2V2_TINY", False), ("W2V2_TINY", True)])
+def test_audio_forward_vs_oracle(cfg_name, ragged, precision, tol):
+    cfg, batch, sd, ae, O = _setup(cfg_name, 3, 1.2, ragged, precision)
+    mask = batch["mask1"] != 3
+    with torch.no_grad():
+        ref_last, ref_mid = O.audio_forward({k: v.clone() for k, v in sd.items()}, cfg, batch["audio"], mask)
+        last, mid = ae(batch["audio"].cuda(), attention_mask=mask.cuda())
+    assert last.shape == ref_last.shape
+    assert float((last.cpu() - ref_last).abs().max()) < tol
+    assert float((mid.cpu() - ref_mid).abs().max()) < tol
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("bf16", 0.1)])
+def test_audio_backward_vs_oracle(precision, tol):
+    cfg, batch, sd, ae, O = _setup("W2V2_TINY", 3, 1.2, True, precision)
+    for n, p in ae.model.named_parameters():
+        p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
+    mask = batch["mask1"] != 3
+    g = torch.Generator().manual_seed(7)
+    osd = {k: v.clone() for k, v in sd.items()}
+    tk = [k for k in osd if any(f"encoder.layers.{i}." in k for i in range(6, 10))]
+    for k in tk:
+        osd[k].requires_grad_(True)
+    ref_last, ref_mid = O.audio_forward(osd, cfg, batch["audio"], mask)
+    wl = torch.randn(ref_last.shape, generator=g); wm = torch.randn(ref_mid.shape, generator=g)
+    ((ref_last * wl).sum() + (ref_mid * wm).sum()).backward()
+    last, mid = ae(batch["audio"].cuda(), attention_mask=mask.cuda())
+    ((last * wl.cuda()).sum() + (mid * wm.cuda()).sum()).backward()
+    worst = 0.0
+    for n, p in ae.named_parameters():
+        if p.requires_grad:
+            ref = osd[n].grad
+            if "k_proj.bias" in n:      # mathematically zero gradient
+                assert float(p.grad.abs().max()) < 1e-2 * max(1.0, float(wl.abs().max()))
+                continue
+            rel = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12))
+            worst = max(worst, rel)
+            assert rel < tol, (n, rel)
+        else:
+            assert p.grad is None
+    print("worst rel grad error", worst)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3)])
+def test_audio_c1_golden(precision, tol):
+    """Full-size wav2vec2-large against the fixture captured from the reference itself (tests/golden/c1.npz)."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1.npz"))
+    cfg, batch, sd, ae, O = _setup("W2V2_LARGE", 2, 1.0, False, precision)
+    ae.eval()
+    with torch.no_grad():
+        last, mid = ae(batch["audio"].cuda(), attention_mask=(batch["mask1"] != 3).cuda())
+    assert float(np.abs(last.cpu().numpy()[..., ::8] - fx["eval_audio_last"]).max()) < tol
+    assert float(np.abs(mid.cpu().numpy()[..., ::8] - fx["eval_audio_mid"]).max()) < tol
