@@ -90,6 +90,7 @@ int av_colsum(const void* x, int xdt, float* out, long long rows, int cols, long
 int av_cast(const void* x, int xdt, void* y, int ydt, long long n, void* stream);
 int av_axpby(float a, const void* x, int xdt, float b, float* y, long long n, void* stream); /* y = a*x + b*y */
 int av_mask_rows(void* x, int xdt, const unsigned char* keep, long long rows, int cols, void* stream); /* hf:752-755 */
+int av_mul_scalar_dev(const float* x, const float* scalar, float* y, long long n, void* stream); /* y = scalar[0]*x, scalar on device */
 
 /* ---- fused attention (flash-style forward) ---------------------------------------------------------------
  * O = softmax(scale*Q K^T + key-padding mask) V, LSE saved.  Replaces hf:438-463 (sdpa, 16 heads x 64) and the
@@ -109,6 +110,47 @@ int av_softmax_bwd_rows(const void* p, int pdt, const float* dp, void* ds, int d
  * wav [B][T_in] fp32 -> out [B][L_out][C] channel-last in out_dtype; w [C][k] fp32. */
 int av_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, void* out,
                      int out_dtype, int B, int T_in, int L_out, int C, int k, int stride, float eps, void* stream);
+
+/* ---- bidirectional LSTM time steps (nn.LSTM(512,512,2,bidirectional), model/fusion_module.py:21-27,64) ----
+ * Time-major internal buffers; both directions advance in one launch (step s: fwd chain at time s, reverse
+ * chain at T-1-s).  gx = x W_ih^T + b_ih + b_hh for all steps comes from av_gemm.  fwd: h,c,(gates) of step s;
+ * bwd (s counts from the END of each chain): dgates[t] from dout[t] + dgates[t_next] W_hh, running dc in place. */
+int av_lstm_fwd_step(const float* gx, const void* whh, void* hseq, float* cseq, void* gates, void* out_bt, int dtype,
+                     int T, int B, int H, int s, void* stream);
+int av_lstm_bwd_step(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgates, const void* whhT,
+                     const void* gates, const float* cseq, float* dc, int dtype, int T, int B, int H, int s, void* stream);
+
+/* ---- fusion glue without host syncs (model/fusion_module.py:40-55,66; model/trainer.py:98,102) ------------- */
+int av_mask_downsample(const long long* mask, long long* out, int B, int Tin, int Tout, void* stream);
+/* ws_i32: B*Ta + B + 1 ints (compaction index, counts, batch max) kept for the backward */
+int av_fusion_gather_lerp_fwd(const float* feat, const long long* mask, int* ws_i32, float* out, long long* mask_out,
+                              long long* lens, int B, int Ta, int Tv, int D, void* stream);
+int av_fusion_gather_lerp_bwd(const float* dout, const int* ws_i32, float* dfeat, int B, int Ta, int Tv, int D, void* stream);
+int av_permute_bt(const void* in, int idt, void* out, int odt, int B, int T, int D, void* stream); /* [B,T,D]->[T,B,D] */
+int av_gather_rows(const void* src, int sdt, const long long* idx, void* out, int odt, long long n, int D, void* stream);
+int av_scatter_rows(const float* src, const long long* idx, float* out, long long n, int D, float alpha, int accumulate,
+                    void* stream);
+
+/* ---- lip-frame encoder glue (model/encoder.py:6-75): train-mode BatchNorm, PReLU, pooling; NHWC ------------ */
+int av_bn_finalize(const float* partial, int nblk, long long count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
+                   float* shift, int C, void* stream);
+int av_bn_act(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
+              const float* rshift, const float* slope, void* out, int dtype, long long n, int C, void* stream);
+int av_bn_prelu_maxpool(const void* x, const float* scale, const float* shift, const float* slope, void* out, int dtype,
+                        long long N, int H, int W, int C, void* stream);
+int av_avgpool(const void* x, int dtype, float* out, long long N, int HW, int C, void* stream);
+
+/* ---- loss / optimizer side (contrastive.py:8-44; torch.optim.Adam, model/trainer.py:34-39) ------------------ */
+int av_l2norm_fwd(const float* x, float* y, float* nrm, long long rows, int cols, float eps, void* stream);
+int av_l2norm_bwd(const float* y, const float* dy, const float* nrm, float* dx, long long rows, int cols, float eps,
+                  void* stream);
+int av_lse_rows(const float* s, float* lse, float* rowsum, long long rows, int cols, int ld, void* stream);
+int av_contrastive_dsim(const float* s, const float* lse, void* out, int odt, long long rows, int cols, int ld, float coef,
+                        void* stream);
+int av_reduce_sum(const float* x, long long n, float* out, float scale, int accumulate, void* stream);
+int av_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                 int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,9 +46,28 @@ SIGNATURES = {
     "av_cast": [vp, i32, vp, i32, ll, vp],
     "av_axpby": [f32, vp, i32, f32, vp, ll, vp],
     "av_mask_rows": [vp, i32, vp, ll, i32, vp],
+    "av_mul_scalar_dev": [vp, vp, vp, ll, vp],
     "av_attention_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ll, ll, ll, ll, ll, ll, ll, ll, vp, f32, vp],
     "av_softmax_rows": [vp, vp, i32, ll, i32, f32, vp, i32, i32, vp],
     "av_conv0_ln_gelu": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "av_lstm_fwd_step": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "av_lstm_bwd_step": [vp, i32, ll, ll, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "av_mask_downsample": [vp, vp, i32, i32, i32, vp],
+    "av_fusion_gather_lerp_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "av_fusion_gather_lerp_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "av_permute_bt": [vp, i32, vp, i32, i32, i32, i32, vp],
+    "av_gather_rows": [vp, i32, vp, vp, i32, ll, i32, vp],
+    "av_scatter_rows": [vp, vp, vp, ll, i32, f32, i32, vp],
+    "av_bn_finalize": [vp, i32, ll, vp, vp, vp, vp, f32, f32, i32, vp, vp, i32, vp],
+    "av_bn_act": [vp, vp, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp],
+    "av_bn_prelu_maxpool": [vp, vp, vp, vp, vp, i32, ll, i32, i32, i32, vp],
+    "av_avgpool": [vp, i32, vp, ll, i32, i32, vp],
+    "av_l2norm_fwd": [vp, vp, vp, ll, i32, f32, vp],
+    "av_l2norm_bwd": [vp, vp, vp, vp, ll, i32, f32, vp],
+    "av_lse_rows": [vp, vp, vp, ll, i32, i32, vp],
+    "av_contrastive_dsim": [vp, vp, vp, i32, ll, i32, i32, f32, vp],
+    "av_reduce_sum": [vp, ll, vp, f32, i32, vp],
+    "av_adam_step": [vp, vp, vp, vp, ll, f32, f32, f32, f32, i32, f32, vp],
     "av_softmax_bwd_rows": [vp, i32, vp, vp, i32, ll, i32, f32, i32, vp],
 }
 _RESTYPES = {"av_last_error": C.c_char_p}

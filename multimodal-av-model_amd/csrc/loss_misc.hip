@@ -1,0 +1,141 @@
+// Small kernels of the loss / optimizer side:
+//   * row L2-normalise fwd/bwd (F.normalize, contrastive.py:22),
+//   * row log-sum-exp + row sum of the similarity matrix and the softmax-minus-uniform gradient of
+//     -log_softmax(sim).mean() (contrastive.py:33-34,41-42),
+//   * scalar reductions,
+//   * fused Adam step (torch.optim.Adam defaults, model/trainer.py:34-39) with optional gradient scaling.
+#include "av_common.h"
+
+namespace {
+
+constexpr int MAXIT = 32;
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ nrm,
+                                                         long long rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long base = row * cols;
+    float q = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = x[base + c]; q += v * v; }
+    const float n = sqrtf(wave_sum(q));
+    const float inv = 1.f / fmaxf(n, eps);
+    for (int c = lane; c < cols; c += 64) y[base + c] = x[base + c] * inv;
+    if (lane == 0) nrm[row] = n;
+}
+// dx = (dy - y (y . dy)) / max(n, eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ nrm,
+                                                         float* __restrict__ dx, long long rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long base = row * cols;
+    float d = 0.f;
+    for (int c = lane; c < cols; c += 64) d += y[base + c] * dy[base + c];
+    d = wave_sum(d);
+    const float inv = 1.f / fmaxf(nrm[row], eps);
+    for (int c = lane; c < cols; c += 64) dx[base + c] = (dy[base + c] - y[base + c] * d) * inv;
+}
+
+__global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ s, float* __restrict__ lse, float* __restrict__ rsum,
+                                                       long long rows, int cols, int ld) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = s + row * ld;
+    float mx = -INFINITY, sm = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = p[c]; mx = fmaxf(mx, v); sm += v; }
+    mx = wave_max(mx);
+    float e = 0.f;
+    for (int c = lane; c < cols; c += 64) e += expf(p[c] - mx);
+    e = wave_sum(e);
+    sm = wave_sum(sm);
+    if (lane == 0) { lse[row] = mx + logf(e); rsum[row] = sm; }
+}
+
+// dsim = coef * (exp(sim - lse_row) - 1/cols)
+__global__ __launch_bounds__(256) void contrastive_dsim_kernel(const float* __restrict__ s, const float* __restrict__ lse, void* __restrict__ out,
+                                                               int odt, long long rows, int cols, int ld, float coef) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float l = lse[row], u = 1.f / (float)cols;
+    for (int c = lane; c < ld; c += 64) st_any(out, row * ld + c, odt, c < cols ? coef * (expf(s[row * ld + c] - l) - u) : 0.f);
+}
+
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, long long n, float* __restrict__ out, float scale, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = scale * (red[0] + red[1] + red[2] + red[3]);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+inline int ew_grid(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" int av_l2norm_fwd(const float* x, float* y, float* nrm, long long rows, int cols, float eps, void* stream) {
+    AV_CHECK(x && y && nrm && cols > 0, "av_l2norm_fwd: bad args");
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, nrm, rows, cols, eps);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_l2norm_bwd(const float* y, const float* dy, const float* nrm, float* dx, long long rows, int cols, float eps, void* stream) {
+    AV_CHECK(y && dy && nrm && dx && cols > 0, "av_l2norm_bwd: bad args");
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, dy, nrm, dx, rows, cols, eps);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_lse_rows(const float* s, float* lse, float* rowsum, long long rows, int cols, int ld, void* stream) {
+    AV_CHECK(s && lse && rowsum && cols > 0 && ld >= cols, "av_lse_rows: bad args");
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(lse_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, rowsum, rows, cols, ld);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_contrastive_dsim(const float* s, const float* lse, void* out, int odt, long long rows, int cols, int ld, float coef, void* stream) {
+    AV_CHECK(s && lse && out && cols > 0 && ld >= cols, "av_contrastive_dsim: bad args");
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(contrastive_dsim_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, out, odt, rows, cols, ld, coef);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_reduce_sum(const float* x, long long n, float* out, float scale, int accumulate, void* stream) {
+    AV_CHECK(x && out, "av_reduce_sum: bad args");
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out, scale, accumulate);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                            int step, float grad_scale, void* stream) {
+    AV_CHECK(p && g && m && v && step >= 1, "av_adam_step: bad args");
+    if (n == 0) return AV_OK;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

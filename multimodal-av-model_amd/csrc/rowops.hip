@@ -200,6 +200,11 @@ __global__ void mask_rows_kernel(void* __restrict__ x, int xdt, const unsigned c
         if (!keep[i / cols]) st_any(x, i, xdt, 0.f);
 }
 
+__global__ void mul_scalar_dev_kernel(const float* __restrict__ x, const float* __restrict__ sc, float* __restrict__ y, long long n) {
+    const float s = sc[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = s * x[i];
+}
+
 inline int ew_grid(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -290,6 +295,14 @@ extern "C" int av_mask_rows(void* x, int xdt, const unsigned char* keep, long lo
     AV_CHECK(x && keep, "av_mask_rows: null pointer");
     if (rows == 0) return AV_OK;
     hipLaunchKernelGGL(mask_rows_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, xdt, keep, rows, (int)cols);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_mul_scalar_dev(const float* x, const float* scalar, float* y, long long n, void* stream) {
+    AV_CHECK(x && scalar && y, "av_mul_scalar_dev: null pointer");
+    if (n == 0) return AV_OK;
+    hipLaunchKernelGGL(mul_scalar_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, scalar, y, n);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

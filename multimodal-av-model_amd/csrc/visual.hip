@@ -1,0 +1,151 @@
+// Lip-frame encoder glue around the implicit-GEMM convolutions (model/encoder.py:6-75), channel-last (NHWC):
+//   * train-mode BatchNorm statistics: finalize the per-block column partials the conv GEMM epilogue wrote
+//     (batch mean / biased variance -> scale, shift; running-stat update with momentum 0.1 and the unbiased
+//     variance — the side effect of calling .train() on the frozen encoder, model/trainer.py:54),
+//   * fused BN-apply + residual (+ its own BN) + PReLU,
+//   * fused BN-apply + PReLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the 3-D front-end,
+//   * AdaptiveAvgPool2d(1).
+// All of them are HBM-bound single-pass kernels with 8/16-byte accesses along the channel dimension.
+#include "av_common.h"
+
+namespace {
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                   float eps, int training, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc, sh;
+    if (training) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            s += (double)part[(long long)b * 2 * C + c];
+            q += (double)part[(long long)b * 2 * C + C + c];
+        }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+        sh = beta[c] - (float)mean * sc;
+        if (rmean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    } else {
+        sc = gamma[c] * rsqrtf(rvar[c] + eps);
+        sh = beta[c] - rmean[c] * sc;
+    }
+    scale[c] = sc;
+    shift[c] = sh;
+}
+
+template <typename T>
+__global__ void bn_act_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                              const T* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
+                              const float* __restrict__ slope, T* __restrict__ out, long long n, int C) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        float v = to_f32<T>(x[e]) * scale[c] + shift[c];
+        if (res) {
+            const float rv = to_f32<T>(res[e]);
+            v += rscale ? rv * rscale[c] + rshift[c] : rv;
+        }
+        if (slope) v = v >= 0.f ? v : v * slope[c];
+        out[e] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void bn_prelu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                        const float* __restrict__ slope, T* __restrict__ out, long long N, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long tot = N * Ho * Wo * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long q = e / C;
+        const int ox = (int)(q % Wo); q /= Wo;
+        const int oy = (int)(q % Ho);
+        const long long img = q / Ho;
+        const float sc = scale[c], sh = shift[c], sl = slope[c];
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if (ix < 0 || ix >= W) continue;
+                float v = to_f32<T>(x[((img * H + iy) * W + ix) * C + c]) * sc + sh;
+                v = v >= 0.f ? v : v * sl;
+                m = fmaxf(m, v);
+            }
+        }
+        out[e] = from_f32<T>(m);
+    }
+}
+
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, long long N, int HW, int C) {
+    const long long tot = N * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long long img = e / C;
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += to_f32<T>(x[(img * HW + p) * C + c]);
+        out[e] = s / (float)HW;
+    }
+}
+
+inline int ew_grid(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int av_bn_finalize(const float* partial, int nblk, long long count, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, int training, float* scale, float* shift, int C, void* stream) {
+    AV_CHECK(gamma && beta && scale && shift && C > 0, "av_bn_finalize: null pointer");
+    AV_CHECK(training ? (partial != nullptr && nblk > 0 && count > 0) : (running_mean && running_var), "av_bn_finalize: missing statistics input");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, (double)count, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, scale, shift, C);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_bn_act(const void* x, const float* scale, const float* shift, const void* res, const float* rscale, const float* rshift,
+                         const float* slope, void* out, int dtype, long long n, int C, void* stream) {
+    AV_CHECK(x && scale && shift && out && C > 0, "av_bn_act: null pointer");
+    if (n == 0) return AV_OK;
+    if (dtype == AV_F32)
+        hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, shift, (const float*)res, rscale, rshift, slope, (float*)out, n, C);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift, (const bf16_t*)res, rscale, rshift, slope, (bf16_t*)out, n, C);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_bn_prelu_maxpool(const void* x, const float* scale, const float* shift, const float* slope, void* out, int dtype,
+                                   long long N, int H, int W, int C, void* stream) {
+    AV_CHECK(x && scale && shift && slope && out, "av_bn_prelu_maxpool: null pointer");
+    if (N == 0) return AV_OK;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long tot = N * Ho * Wo * C;
+    if (dtype == AV_F32)
+        hipLaunchKernelGGL(bn_prelu_maxpool_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, shift, slope, (float*)out, N, H, W, C);
+    else
+        hipLaunchKernelGGL(bn_prelu_maxpool_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift, slope, (bf16_t*)out, N, H, W, C);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_avgpool(const void* x, int dtype, float* out, long long N, int HW, int C, void* stream) {
+    AV_CHECK(x && out && HW > 0 && C > 0, "av_avgpool: bad args");
+    if (N == 0) return AV_OK;
+    if (dtype == AV_F32) hipLaunchKernelGGL(avgpool_kernel<float>, dim3(ew_grid(N * C)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, N, HW, C);
+    else hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(ew_grid(N * C)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, N, HW, C);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

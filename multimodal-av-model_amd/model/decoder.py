@@ -1,0 +1,52 @@
+"""CTCDecoder on the HIP kernels (model/decoder.py:6-35): Linear(input_dim -> vocab) + log_softmax as one MFMA
+GEMM + a wavefront-per-row log-softmax.  nn.CTCLoss itself stays on PyTorch-ROCm (BASELINE north_star).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..precision import compute_dtype
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, x, w, b):
+        dtype = compute_dtype()
+        xt = ops.cast(x.contiguous().float(), dtype)
+        wt = ops.cast(w.data.contiguous(), dtype)
+        logits = ops.linear(xt, wt, b.data, out_dtype=torch.float32)
+        lp = ops.log_softmax_fwd(logits)
+        fctx.save_for_backward(xt, wt, lp)
+        fctx.dtype = dtype
+        return lp
+
+    @staticmethod
+    def backward(fctx, dlp):
+        xt, wt, lp = fctx.saved_tensors
+        V, D = wt.shape
+        dlogits = ops.log_softmax_bwd(lp, dlp.contiguous().float(), fctx.dtype)
+        d2 = dlogits.view(-1, V)
+        dx = ops.matmul_nn(d2, wt, out_dtype=torch.float32).view(xt.shape) if fctx.needs_input_grad[0] else None
+        dw = ops.matmul_tn(d2, xt.view(-1, D)) if fctx.needs_input_grad[1] else None
+        db = ops.colsum(d2) if fctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class CTCDecoder(nn.Module):
+    def __init__(self, input_dim, vocab_size, blank_id=0):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(input_dim, vocab_size))     # parameter container: keys net.0.{weight,bias}
+        self.ctc_loss = nn.CTCLoss(blank=blank_id, zero_infinity=True)
+
+    def forward(self, x, target=None, input_lengths=None, target_lengths=None):
+        """x [B,T,D] -> log-probs [B,T,V], or the CTC loss when ``target`` is given (model/decoder.py:14-35)."""
+        if not x.is_cuda:
+            raise RuntimeError("CTCDecoder (HIP): input must be on the GPU; there is no CPU fallback")
+        lin = self.net[0]
+        log_probs = _HeadFn.apply(x, lin.weight, lin.bias)
+        if target is not None:
+            return self.ctc_loss(log_probs.transpose(0, 1), target, input_lengths, target_lengths)
+        return log_probs

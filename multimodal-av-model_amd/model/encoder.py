@@ -47,3 +47,163 @@ class AudioEncoder(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("AudioEncoder (HIP): input must be on the GPU; there is no CPU fallback")
         return w2v2_apply(self.model, x, attention_mask)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Visual encoder (model/encoder.py:6-75): Conv3d front-end + ResNet-18 trunk, BatchNorm + PReLU, applied per frame.
+# torch.nn modules below are parameter/buffer CONTAINERS that reproduce the checkpoint keys
+# (frontend3D.{0,1,2}.*, trunk.layerN.M.{conv1,bn1,relu,conv2,bn2,downsample.0,downsample.1}.*); the arithmetic
+# runs in VisualEncoder.forward on implicit-GEMM MFMA convolutions over channel-last (NHWC) activations.
+# ---------------------------------------------------------------------------------------------------------------
+from .. import _lib as L          # noqa: E402
+from .. import ops                # noqa: E402
+from ..precision import compute_dtype  # noqa: E402
+
+_TRUNK = ((64, 1), (128, 2), (256, 2), (512, 2))      # (planes, stride of the first block) for layer1..4
+
+
+class BasicBlock(nn.Module):
+    """Container for one residual block: conv3x3-BN-PReLU-conv3x3-BN (+1x1 conv-BN shortcut) -> add -> PReLU.
+    A single PReLU (``relu``) serves both activations, as in the reference (model/encoder.py:11,18,22)."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, relu_type="prelu"):
+        super().__init__()
+        if relu_type != "prelu":
+            raise NotImplementedError("the HIP visual encoder implements relu_type='prelu' (what main.py:92 uses)")
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.PReLU(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet(nn.Module):
+    def __init__(self, block=BasicBlock, layers=(2, 2, 2, 2), relu_type="prelu"):
+        super().__init__()
+        inpl = 64
+        for li, ((planes, stride), nblk) in enumerate(zip(_TRUNK, layers), start=1):
+            blocks = []
+            for bi in range(nblk):
+                st = stride if bi == 0 else 1
+                ds = None
+                if st != 1 or inpl != planes:
+                    ds = nn.Sequential(nn.Conv2d(inpl, planes, 1, st, bias=False), nn.BatchNorm2d(planes))
+                blocks.append(block(inpl, planes, st, ds, relu_type))
+                inpl = planes
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+
+
+class VisualEncoder(nn.Module):
+    def __init__(self, relu_type="prelu"):
+        super().__init__()
+        if relu_type != "prelu":
+            raise NotImplementedError("the HIP visual encoder implements relu_type='prelu'")
+        self.frontend3D = nn.Sequential(
+            nn.Conv3d(1, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
+            nn.BatchNorm3d(64), nn.PReLU(64), nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)))
+        self.trunk = ResNet(BasicBlock, [2, 2, 2, 2], relu_type=relu_type)
+        self.output_dim = 512
+        self._wcache = {}
+
+    # conv weight [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin] (tap-major K = the NHWC im2col order), compute dtype, cached
+    def _w(self, conv: nn.Module, dtype):
+        p = conv.weight
+        key = id(p)
+        ver = (p._version, p.data_ptr(), dtype)
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                if p.dim() == 5:
+                    w = p.data.reshape(p.shape[0], -1)
+                else:
+                    w = p.data.permute(0, 2, 3, 1).reshape(p.shape[0], -1)
+                hit = (ver, ops.cast(w.contiguous(), dtype))
+            self._wcache[key] = hit
+        return hit[1]
+
+    def _bn(self, bn: nn.Module, stats, nblk: int, count: int, training: bool):
+        C = bn.num_features
+        dev = bn.weight.device
+        scale = torch.empty(C, dtype=torch.float32, device=dev); shift = torch.empty(C, dtype=torch.float32, device=dev)
+        L.check(L.lib().av_bn_finalize(ops.ptr(stats), nblk, count, ops.ptr(bn.weight.data), ops.ptr(bn.bias.data),
+                                       ops.ptr(bn.running_mean), ops.ptr(bn.running_var), float(bn.momentum), float(bn.eps),
+                                       int(training), ops.ptr(scale), ops.ptr(shift), C, ops.stream()), "av_bn_finalize")
+        if training:
+            bn.num_batches_tracked += 1
+        return scale, shift
+
+    def _conv2d(self, x, N, H, W, Cin, conv: nn.Module, dtype, training: bool):
+        k, st = conv.kernel_size[0], conv.stride[0]
+        pad = conv.padding[0]
+        Cout = conv.out_channels
+        Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+        M = N * Ho * Wo
+        y = torch.empty((M, Cout), dtype=dtype, device=x.device)
+        nblk = (M + 127) // 128
+        stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device) if training else None
+        geo = dict(cT=1, cH=H, cW=W, cCtot=Cin, cCin=Cin, cCoff=0, cKt=1, cKh=k, cKw=k, cSh=st, cSw=st, cPt=0, cPh=pad, cPw=pad,
+                   cOh=Ho, cOw=Wo)
+        ops.gemm(x, self._w(conv, dtype), y, M=M, N=Cout, K=k * k * Cin, lda=0, ldb=k * k * Cin, ldc=Cout, a_mode=L.A_CONV2D,
+                 conv=geo, stats=stats)
+        return y, stats, nblk, M, Ho, Wo
+
+    def _act(self, x, scale, shift, slope, res=None, rscale=None, rshift=None):
+        out = torch.empty_like(x)
+        L.check(L.lib().av_bn_act(ops.ptr(x), ops.ptr(scale), ops.ptr(shift), ops.ptr(res), ops.ptr(rscale), ops.ptr(rshift),
+                                  ops.ptr(slope), ops.ptr(out), ops.dt(x), x.numel(), x.shape[-1], ops.stream()), "av_bn_act")
+        return out
+
+    @torch.no_grad()
+    def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
+        dtype = compute_dtype()
+        training = self.training            # .train() on the frozen encoder => batch statistics + running-stat update
+        B, C, T, H, W = x.shape
+        assert C == 1
+        dev = x.device
+        xin = ops.cast(x.contiguous().float().view(B, T, H, W), dtype)
+        conv0 = self.frontend3D[0]
+        kt, kh, kw = conv0.kernel_size
+        Ho, Wo = (H + 2 * conv0.padding[1] - kh) // conv0.stride[1] + 1, (W + 2 * conv0.padding[2] - kw) // conv0.stride[2] + 1
+        M = B * T * Ho * Wo
+        y = torch.empty((M, 64), dtype=dtype, device=dev)
+        nblk = (M + 127) // 128
+        stats = torch.empty((nblk, 2, 64), dtype=torch.float32, device=dev) if training else None
+        geo = dict(cT=T, cH=H, cW=W, cCtot=1, cCin=1, cCoff=0, cKt=kt, cKh=kh, cKw=kw, cSh=conv0.stride[1], cSw=conv0.stride[2],
+                   cPt=conv0.padding[0], cPh=conv0.padding[1], cPw=conv0.padding[2], cOh=Ho, cOw=Wo)
+        ops.gemm(xin, self._w(conv0, dtype), y, M=M, N=64, K=kt * kh * kw, lda=0, ldb=kt * kh * kw, ldc=64, a_mode=L.A_CONV3D1,
+                 conv=geo, stats=stats)
+        sc, sh = self._bn(self.frontend3D[1], stats, nblk, M, training)
+        N = B * T
+        Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        h = torch.empty((N * Hp * Wp, 64), dtype=dtype, device=dev)
+        L.check(L.lib().av_bn_prelu_maxpool(ops.ptr(y), ops.ptr(sc), ops.ptr(sh), ops.ptr(self.frontend3D[2].weight.data), ops.ptr(h),
+                                            ops.dt(h), N, Ho, Wo, 64, ops.stream()), "av_bn_prelu_maxpool")
+        Hc, Wc, Cc = Hp, Wp, 64
+        for li in range(1, 5):
+            for blk in getattr(self.trunk, f"layer{li}"):
+                slope = blk.relu.weight.data
+                c1, st1, nb1, M1, H1, W1 = self._conv2d(h, N, Hc, Wc, Cc, blk.conv1, dtype, training)
+                s1, b1 = self._bn(blk.bn1, st1, nb1, M1, training)
+                a1 = self._act(c1, s1, b1, slope)
+                c2, st2, nb2, M2, _, _ = self._conv2d(a1, N, H1, W1, blk.conv1.out_channels, blk.conv2, dtype, training)
+                s2, b2 = self._bn(blk.bn2, st2, nb2, M2, training)
+                if blk.downsample is not None:
+                    cd, std, nbd, Md, _, _ = self._conv2d(h, N, Hc, Wc, Cc, blk.downsample[0], dtype, training)
+                    sd, bd = self._bn(blk.downsample[1], std, nbd, Md, training)
+                    h = self._act(c2, s2, b2, slope, res=cd, rscale=sd, rshift=bd)
+                else:
+                    h = self._act(c2, s2, b2, slope, res=h)
+                Hc, Wc, Cc = H1, W1, blk.conv1.out_channels
+        out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+        L.check(L.lib().av_avgpool(ops.ptr(h), ops.dt(h), ops.ptr(out), N, Hc * Wc, Cc, ops.stream()), "av_avgpool")
+        return out.view(B, T, Cc)
+
+    def forward(self, x):
+        """x [B,1,T,96,96] -> [B,T,512] (model/encoder.py:69-75)."""
+        if not x.is_cuda:
+            raise RuntimeError("VisualEncoder (HIP): input must be on the GPU; there is no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the HIP visual encoder is forward-only: freeze trunk and frontend3D as main.py:100-103 does")
+        return self._forward_impl(x)

@@ -1,0 +1,244 @@
+"""CrossAttentionFusion on the HIP kernels — same constructor / forward contract and state_dict keys as the
+reference (model/fusion_module.py:5-67): speech-frame gather -> linear resample to T_v -> two projections ->
+ONE cross-attention (audio queries, visual keys/values, 4 heads) -> Linear -> 2-layer BiLSTM(512).
+
+torch.nn modules are used ONLY as parameter containers (names + default init); their forward is never called.
+Forward and backward are explicit kernel sequences; the data-dependent gather/pad/interpolate and the CTC
+``input_lengths`` are computed on the device without host syncs.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+from ..precision import compute_dtype
+
+Tensor = torch.Tensor
+
+
+class _ParamCache:
+    def __init__(self):
+        self.d = {}
+
+    def get(self, key, params, dtype, fn):
+        ver = tuple((p._version, p.data_ptr()) for p in params) + (dtype,)
+        hit = self.d.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                hit = (ver, fn())
+            self.d[key] = hit
+        return hit[1]
+
+
+def lstm_forward(mod: "CrossAttentionFusion", x_tm: Tensor, save: bool):
+    """x_tm [T,B,E] compute dtype -> (out_bt [B,T,2H] compute dtype, ctx)."""
+    lstm = mod.temporal_model
+    dtype = x_tm.dtype
+    T, B, _ = x_tm.shape
+    H = lstm.hidden_size
+    dev = x_tm.device
+    layers = []
+    inp = x_tm
+    out_bt = None
+    for layer in range(lstm.num_layers):
+        names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse", f"weight_hh_l{layer}", f"weight_hh_l{layer}_reverse",
+                 f"bias_ih_l{layer}", f"bias_ih_l{layer}_reverse", f"bias_hh_l{layer}", f"bias_hh_l{layer}_reverse"]
+        P = [getattr(lstm, n) for n in names]
+        wih = mod._cache.get(("wih", layer), P[0:2], dtype, lambda: ops.cast(torch.cat([P[0].data, P[1].data], 0).contiguous(), dtype))
+        whh = mod._cache.get(("whh", layer), P[2:4], dtype, lambda: ops.cast(torch.stack([P[2].data, P[3].data], 0).contiguous(), dtype))
+        bias = mod._cache.get(("b", layer), P[4:8], torch.float32,
+                              lambda: torch.cat([P[4].data + P[6].data, P[5].data + P[7].data], 0).contiguous())
+        gx = ops.linear(inp, wih, bias, out_dtype=torch.float32)                         # [T,B,8H] = [T,B,2,4H]
+        hseq = torch.empty((T, B, 2 * H), dtype=dtype, device=dev)
+        cseq = torch.empty((T, B, 2, H), dtype=torch.float32, device=dev)
+        gates = torch.empty((T, B, 2, 4 * H), dtype=dtype, device=dev) if save else None
+        last = layer == lstm.num_layers - 1
+        if last:
+            out_bt = torch.empty((B, T, 2 * H), dtype=dtype, device=dev)
+        st = ops.stream()
+        fn = L.lib().av_lstm_fwd_step
+        for s in range(T):
+            L.check(fn(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates), ops.ptr(out_bt) if last else None,
+                       ops.dt(hseq), T, B, H, s, st), "av_lstm_fwd_step")
+        if save:
+            layers.append(dict(inp=inp, hseq=hseq, cseq=cseq, gates=gates, wih=wih, whh=whh, names=names))
+        inp = hseq
+    return out_bt, (layers if save else None)
+
+
+def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: Dict[str, Tensor]) -> Tensor:
+    """dout_bt [B,T,2H] fp32 -> d(x_tm) [T,B,E] compute dtype; fills ``grads`` with temporal_model.* gradients."""
+    lstm = mod.temporal_model
+    H = lstm.hidden_size
+    dout, do_bs, do_ts = dout_bt, dout_bt.shape[1] * 2 * H, 2 * H
+    dx = None
+    for layer in range(lstm.num_layers - 1, -1, -1):
+        c = layers[layer]
+        hseq, gates, cseq, inp = c["hseq"], c["gates"], c["cseq"], c["inp"]
+        T, B, _ = hseq.shape
+        dtype = hseq.dtype
+        dev = hseq.device
+        whhT = ops.cast(c["whh"].transpose(1, 2).contiguous(), dtype)                    # [2][H][4H]
+        dgates = torch.empty((T, B, 2, 4 * H), dtype=dtype, device=dev)
+        dc = torch.empty((2, B, H), dtype=torch.float32, device=dev)
+        st = ops.stream()
+        fn = L.lib().av_lstm_bwd_step
+        for s in range(T):
+            L.check(fn(ops.ptr(dout), ops.dt(dout), do_bs, do_ts, ops.ptr(dgates), ops.ptr(whhT), ops.ptr(gates), ops.ptr(cseq),
+                       ops.ptr(dc), ops.dt(dgates), T, B, H, s, st), "av_lstm_bwd_step")
+        M = T * B
+        dg2 = dgates.view(M, 8 * H)
+        in_f = inp.shape[-1]
+        dwih = ops.matmul_tn(dg2, inp.view(M, in_f))                                     # [8H, in]
+        db = ops.colsum(dg2)                                                             # [8H]
+        n = c["names"]
+        grads["temporal_model." + n[0]] = dwih[:4 * H]
+        grads["temporal_model." + n[1]] = dwih[4 * H:]
+        grads["temporal_model." + n[4]] = db[:4 * H]; grads["temporal_model." + n[6]] = db[:4 * H]
+        grads["temporal_model." + n[5]] = db[4 * H:]; grads["temporal_model." + n[7]] = db[4 * H:]
+        dwhh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
+        if T > 1:
+            K = (T - 1) * B
+            # forward chain: dgates[t] pairs with h[t-1]; reverse chain: dgates[t] pairs with h[t+1]
+            ops.gemm(dgates, hseq, dwhh, M=4 * H, N=H, K=K, lda=8 * H, ldb=2 * H, ldc=H, a_mode=L.A_TRANS, b_mode=L.B_KN,
+                     a_off=B * 8 * H, b_off=0, c_off=0)
+            ops.gemm(dgates, hseq, dwhh, M=4 * H, N=H, K=K, lda=8 * H, ldb=2 * H, ldc=H, a_mode=L.A_TRANS, b_mode=L.B_KN,
+                     a_off=4 * H, b_off=B * 2 * H + H, c_off=4 * H * H)
+        grads["temporal_model." + n[2]] = dwhh[0]
+        grads["temporal_model." + n[3]] = dwhh[1]
+        dx = ops.matmul_nn(dg2, c["wih"], out_dtype=dtype).view(T, B, in_f)              # time-major
+        dout, do_bs, do_ts = dx, in_f, B * in_f                                          # next (lower) layer reads time-major
+    return dx
+
+
+class _FusionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, mod: "CrossAttentionFusion", save: bool, names, visual_feat, audio_feat, mask, *params):
+        dtype = compute_dtype()
+        dev = audio_feat.device
+        E, nh = mod.fused_dim, mod.num_heads
+        hd = E // nh
+        B, Tv, Dv = visual_feat.shape
+        _, Ta, Da = audio_feat.shape
+        af = audio_feat.contiguous().float()
+        mask = mask.contiguous().long()
+        ws = torch.empty(B * Ta + B + 1, dtype=torch.int32, device=dev)
+        a_in = torch.empty((B, Tv, Da), dtype=torch.float32, device=dev)
+        m_out = torch.empty((B, Tv), dtype=torch.long, device=dev)
+        lens = torch.empty((B,), dtype=torch.long, device=dev)
+        L.check(L.lib().av_fusion_gather_lerp_fwd(ops.ptr(af), ops.ptr(mask), ops.ptr(ws), ops.ptr(a_in), ops.ptr(m_out), ops.ptr(lens),
+                                                  B, Ta, Tv, Da, ops.stream()), "av_fusion_gather_lerp_fwd")
+        c = lambda p: mod.cparam(p, dtype)
+        vis_t = ops.cast(visual_feat.contiguous().float(), dtype)
+        a_in_t = ops.cast(a_in, dtype)
+        v = ops.linear(vis_t, c(mod.visual_proj.weight), mod.visual_proj.bias.data)
+        a = ops.linear(a_in_t, c(mod.audio_proj.weight), mod.audio_proj.bias.data)
+        mha = mod.cross_attn_audio
+        Win = c(mha.in_proj_weight)
+        bin_ = mha.in_proj_bias.data
+        q = ops.linear(a, Win[:E], bin_[:E].contiguous()).view(B, Tv, nh, hd)
+        kv = ops.linear(v, Win[E:], bin_[E:].contiguous()).view(B, Tv, 2, nh, hd)
+        scale = hd ** -0.5                                   # torch scales q by 1/sqrt(hd) (torch:functional.py:6578)
+        o, _ = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], None, scale, need_lse=False)
+        a2v = ops.linear(o.view(B, Tv, E), c(mha.out_proj.weight), mha.out_proj.bias.data)
+        fused = ops.linear(a2v, c(mod.fusion_proj.weight), mod.fusion_proj.bias.data)
+        x_tm = torch.empty((Tv, B, E), dtype=dtype, device=dev)
+        L.check(L.lib().av_permute_bt(ops.ptr(fused), ops.dt(fused), ops.ptr(x_tm), ops.dt(x_tm), B, Tv, E, ops.stream()), "av_permute_bt")
+        out_bt, lctx = lstm_forward(mod, x_tm, save)
+        out = ops.cast(out_bt, torch.float32)
+        if save:
+            fctx.saved = dict(ws=ws, vis_t=vis_t, a_in_t=a_in_t, v=v, a=a, q=q, kv=kv, o=o, a2v=a2v, fused=fused, lstm=lctx,
+                              shape=(B, Tv, Ta, Da, Dv), dtype=dtype)
+        else:
+            fctx.saved = None
+        fctx.mod, fctx.names = mod, names
+        fctx.need_audio = audio_feat.requires_grad
+        fctx.need_visual = visual_feat.requires_grad
+        fctx.mark_non_differentiable(lens, m_out)
+        return out, lens, m_out
+
+    @staticmethod
+    def backward(fctx, dout, _dl, _dm):
+        mod, s = fctx.mod, fctx.saved
+        n_extra = 6
+        if s is None:
+            return (None,) * (n_extra + len(fctx.names))
+        B, Tv, Ta, Da, Dv = s["shape"]
+        dtype = s["dtype"]
+        E, nh = mod.fused_dim, mod.num_heads
+        hd = E // nh
+        M = B * Tv
+        c = lambda p: mod.cparam(p, dtype)
+        g: Dict[str, Tensor] = {}
+        dx_tm = lstm_backward(mod, s["lstm"], dout.contiguous().float(), g)               # [Tv,B,E]
+        dfused = torch.empty((B, Tv, E), dtype=dtype, device=dout.device)
+        L.check(L.lib().av_permute_bt(ops.ptr(dx_tm), ops.dt(dx_tm), ops.ptr(dfused), ops.dt(dfused), Tv, B, E, ops.stream()), "av_permute_bt")
+        df2 = dfused.view(M, E)
+        g["fusion_proj.weight"] = ops.matmul_tn(df2, s["a2v"].view(M, E)); g["fusion_proj.bias"] = ops.colsum(df2)
+        da2v = ops.matmul_nn(df2, c(mod.fusion_proj.weight))
+        mha = mod.cross_attn_audio
+        g["cross_attn_audio.out_proj.weight"] = ops.matmul_tn(da2v, s["o"].view(M, E)); g["cross_attn_audio.out_proj.bias"] = ops.colsum(da2v)
+        do = ops.matmul_nn(da2v, c(mha.out_proj.weight)).view(B, Tv, nh, hd)
+        q, kv = s["q"], s["kv"]
+        dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+        ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], do, dq, dkv[:, :, 0], dkv[:, :, 1], None, hd ** -0.5)
+        Win = c(mha.in_proj_weight)
+        dq2, dkv2 = dq.view(M, E), dkv.view(M, 2 * E)
+        dWin = torch.empty((3 * E, E), dtype=torch.float32, device=dout.device)
+        ops.matmul_tn(dq2, s["a"].view(M, E), out=dWin[:E])
+        ops.matmul_tn(dkv2, s["v"].view(M, E), out=dWin[E:])
+        g["cross_attn_audio.in_proj_weight"] = dWin
+        g["cross_attn_audio.in_proj_bias"] = torch.cat([ops.colsum(dq2), ops.colsum(dkv2)])
+        da = ops.matmul_nn(dq2, Win[:E])
+        dv = ops.matmul_nn(dkv2, Win[E:])
+        g["audio_proj.weight"] = ops.matmul_tn(da, s["a_in_t"].view(M, Da)); g["audio_proj.bias"] = ops.colsum(da)
+        g["visual_proj.weight"] = ops.matmul_tn(dv, s["vis_t"].view(M, Dv)); g["visual_proj.bias"] = ops.colsum(dv)
+        d_audio = d_visual = None
+        if fctx.need_audio:
+            da_in = ops.matmul_nn(da, c(mod.audio_proj.weight), out_dtype=torch.float32)       # [M, Da]
+            d_audio = torch.empty((B, Ta, Da), dtype=torch.float32, device=dout.device)
+            L.check(L.lib().av_fusion_gather_lerp_bwd(ops.ptr(da_in), ops.ptr(s["ws"]), ops.ptr(d_audio), B, Ta, Tv, Da, ops.stream()),
+                    "av_fusion_gather_lerp_bwd")
+        if fctx.need_visual:
+            d_visual = ops.matmul_nn(dv, c(mod.visual_proj.weight), out_dtype=torch.float32).view(B, Tv, Dv)
+        fctx.saved = None
+        return (None, None, None, d_visual, d_audio, None) + tuple(g.get(n) for n in fctx.names)
+
+
+class CrossAttentionFusion(nn.Module):
+    def __init__(self, visual_dim, audio_dim, fused_dim, num_heads=4):
+        super().__init__()
+        self.visual_proj = nn.Linear(visual_dim, fused_dim)
+        self.audio_proj = nn.Linear(audio_dim, fused_dim)
+        # declared by the reference but never called (model/fusion_module.py:14 vs :61): kept for the checkpoint keys
+        self.cross_attn_visual = nn.MultiheadAttention(embed_dim=fused_dim, num_heads=num_heads, batch_first=True)
+        self.cross_attn_audio = nn.MultiheadAttention(embed_dim=fused_dim, num_heads=num_heads, batch_first=True)
+        self.fusion_proj = nn.Linear(fused_dim, fused_dim)
+        self.temporal_model = nn.LSTM(input_size=fused_dim, hidden_size=fused_dim, num_layers=2, batch_first=True, bidirectional=True)
+        self.fused_dim, self.num_heads = fused_dim, num_heads
+        self._cache = _ParamCache()
+        if fused_dim % 32 or (fused_dim // num_heads) not in (16, 32, 64, 128):
+            raise ValueError("fused_dim must be a multiple of 32 with head_dim in {16,32,64,128} for the HIP kernels")
+
+    def cparam(self, p: Tensor, dtype) -> Tensor:
+        if dtype == torch.float32:
+            return p.data
+        return self._cache.get(("c", id(p)), [p], dtype, lambda: ops.cast(p.data.contiguous(), dtype))
+
+    def forward(self, visual_feat, audio_feat, mask=None):
+        """visual_feat [B,T_v,D_v], audio_feat [B,T_a,D_a], mask [B,T_a] (0/3 ignore, 1/2 use) ->
+        (fused [B,T_v,2*fused_dim], input_lengths int64 [B] on mask.device)"""
+        if mask is None:
+            raise ValueError("CrossAttentionFusion: mask is required (the reference dereferences it unconditionally, :66)")
+        if not audio_feat.is_cuda:
+            raise RuntimeError("CrossAttentionFusion (HIP): inputs must be on the GPU; there is no CPU fallback")
+        names = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("cross_attn_visual.")]
+        params = [dict(self.named_parameters())[n] for n in names]
+        save = torch.is_grad_enabled() and (bool(names) or audio_feat.requires_grad or visual_feat.requires_grad)
+        out, lens, m_out = _FusionFn.apply(self, save, names, visual_feat, audio_feat, mask, *params)
+        self.last_mask = m_out
+        return out, lens

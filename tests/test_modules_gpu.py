@@ -1,0 +1,164 @@
+"""GPU parity of the HIP modules (visual encoder, fusion incl. BiLSTM, CTC head, contrastive loss, Adam) vs the oracle."""
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(precision):
+    pkg("precision").set_precision(precision)
+
+
+def _clone(sd):
+    return {k: v.clone() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 0.12)])
+@pytest.mark.parametrize("training", [True, False])
+def test_visual_encoder(precision, tol, training):
+    _p(precision)
+    from oracle import av_oracle as O
+    init = pkg("utils.init"); enc = pkg("model.encoder")
+    sd = init.visual_state_dict()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 1, 5, 96, 96, generator=g)
+    osd = _clone(sd)
+    with torch.no_grad():
+        ref = O.visual_forward(osd, x, training)
+    ve = enc.VisualEncoder().cuda()
+    ve.load_state_dict(sd)
+    for p in ve.parameters():
+        p.requires_grad = False
+    ve.train(training)
+    out = ve(x.cuda())
+    assert out.shape == (2, 5, 512)
+    err = float((out.cpu() - ref).abs().max())
+    print("visual max err", precision, training, err, "ref scale", float(ref.abs().max()))
+    assert err < tol * max(1.0, float(ref.abs().max()))
+    if training:   # running statistics side effect (model/trainer.py:54)
+        now = ve.state_dict()
+        for k in ("frontend3D.1.running_mean", "frontend3D.1.running_var", "trunk.layer4.1.bn2.running_var", "trunk.layer2.0.downsample.1.running_mean"):
+            assert float((now[k].cpu() - osd[k]).abs().max()) < (2e-4 if precision == "fp32" else 5e-2), k
+        assert int(now["frontend3D.1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("precision,tol,gtol", [("fp32", 1e-3, 2e-3), ("bf16", 6e-2, 0.1)])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_fusion_fwd_bwd(precision, tol, gtol, ragged):
+    _p(precision)
+    from oracle import av_oracle as O
+    init = pkg("utils.init"); fm = pkg("model.fusion_module")
+    B, Tv, Ta, Da = 3, 30, 59, 64
+    g = torch.Generator().manual_seed(5)
+    vis = torch.randn(B, Tv, 512, generator=g); aud = torch.randn(B, Ta, Da, generator=g)
+    mask = torch.ones(B, Ta, dtype=torch.long)
+    mask[:, 44:] = 2
+    if ragged:
+        mask[1, 30:] = 3; mask[1, 20:30] = 0; mask[2, 50:] = 3; mask[2, :5] = 0
+    else:
+        mask[:, 40:] = 0          # speaker-2 style: 1 then 0
+    sd = init.fusion_state_dict(512, Da, 512)
+    osd = _clone(sd)
+    used = [k for k in osd if not k.startswith("cross_attn_visual.")]
+    for k in used:
+        osd[k].requires_grad_(True)
+    aud_r = aud.clone().requires_grad_(True)
+    ref, ref_len = O.fusion_forward(osd, vis, aud_r, mask)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    mod = fm.CrossAttentionFusion(512, Da, 512).cuda()
+    mod.load_state_dict(sd)
+    aud_c = aud.cuda().requires_grad_(True)
+    out, lens = mod(vis.cuda(), aud_c, mask.cuda())
+    assert torch.equal(lens.cpu(), ref_len), (lens, ref_len)
+    err = float((out.cpu() - ref).abs().max())
+    print("fusion fwd err", err)
+    assert err < tol
+    (out * w.cuda()).sum().backward()
+    worst = 0.0
+    for n, p in mod.named_parameters():
+        if n.startswith("cross_attn_visual."):
+            assert p.grad is None
+            continue
+        rel = float((p.grad.cpu() - osd[n].grad).norm() / (osd[n].grad.norm() + 1e-12))
+        worst = max(worst, rel)
+        assert rel < gtol, (n, rel)
+    rel = float((aud_c.grad.cpu() - aud_r.grad).norm() / (aud_r.grad.norm() + 1e-12))
+    print("fusion worst param-grad rel", worst, "audio-grad rel", rel)
+    assert rel < gtol
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_decoder_fwd_bwd(precision, tol):
+    _p(precision)
+    from oracle import av_oracle as O
+    init = pkg("utils.init"); dm = pkg("model.decoder")
+    sd = init.decoder_state_dict(1024, 800)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 25, 1024, generator=g) * 0.2
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.decoder_forward(osd, xr)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    d = dm.CTCDecoder(1024, 800, 3).cuda(); d.load_state_dict(sd)
+    xc = x.cuda().requires_grad_(True)
+    out = d(xc)
+    assert float((out.cpu() - ref).abs().max()) < tol
+    (out * w.cuda()).sum().backward()
+    for n, p in d.named_parameters():
+        rel = float((p.grad.cpu() - osd[n].grad).norm() / osd[n].grad.norm())
+        assert rel < (2e-4 if precision == "fp32" else 3e-2), (n, rel)
+    assert float((xc.grad.cpu() - xr.grad).norm() / xr.grad.norm()) < (2e-4 if precision == "fp32" else 3e-2)
+    # CTC branch (stays on PyTorch-ROCm)
+    tgt = torch.randint(4, 800, (2, 5)); il = torch.tensor([25, 20]); tl = torch.tensor([5, 3])
+    loss = d(xc, tgt.cuda(), il.cuda(), tl.cuda())
+    ref_loss = O.ctc_loss(ref.detach(), tgt, il, tl, 3)
+    assert abs(float(loss) - float(ref_loss)) < (1e-3 if precision == "fp32" else 0.3)
+
+
+@pytest.mark.parametrize("precision,tol,gtol", [("fp32", 1e-4, 1e-3), ("bf16", 5e-2, 0.1)])
+@pytest.mark.parametrize("with_pad", [False, True])
+def test_contrastive_fwd_bwd(precision, tol, gtol, with_pad):
+    _p(precision)
+    from oracle import av_oracle as O
+    init = pkg("utils.init"); con = pkg("contrastive")
+    B, T, D = 3, 49, 64
+    g = torch.Generator().manual_seed(8)
+    mid = torch.randn(B, T, D, generator=g)
+    m = torch.ones(B, T, dtype=torch.long); m[:, 30:] = 2; m[1, 20:] = 0
+    if with_pad:
+        m[2, 40:] = 3
+    pw, pb = init.projection_params(D)
+    mr = mid.clone().requires_grad_(True)
+    ref = O.contrastive(mr, m.reshape(-1), pw, pb)
+    ref.backward()
+    proj = torch.nn.Linear(D, 128).cuda()
+    with torch.no_grad():
+        proj.weight.copy_(pw); proj.bias.copy_(pb)
+    mc = mid.cuda().requires_grad_(True)
+    for counts in (None, (int((m == 1).sum()), int((m == 2).sum()), int((m == 0).sum()))):
+        mc.grad = None
+        out = con.contrastive_loss_with_mask(mc, m.reshape(-1).cuda(), projection_layer=proj, counts=counts)
+        assert abs(float(out) - float(ref)) < tol * max(1.0, abs(float(ref))), (float(out), float(ref))
+        (out * 0.05).backward()
+        rel = float((mc.grad.cpu() / 0.05 - mr.grad).norm() / mr.grad.norm())
+        print("contrastive", precision, float(out), float(ref), "grad rel", rel)
+        assert rel < gtol
+
+
+def test_adam_step_matches_torch():
+    L = pkg("_lib"); ops = pkg("ops")
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(1000, 33, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-5)
+    pc = p0.clone().cuda(); m = torch.zeros_like(pc); v = torch.zeros_like(pc)
+    for step in range(1, 4):
+        gr = torch.randn(1000, 33, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        L.check(L.lib().av_adam_step(ops.ptr(pc), ops.ptr(gr.cuda()), ops.ptr(m), ops.ptr(v), pc.numel(), 2e-5, 0.9, 0.999, 1e-8, step, 1.0, ops.stream()))
+    torch.testing.assert_close(pc.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
