@@ -1,0 +1,38 @@
+"""Decoding helpers with the reference's names (beam_search.py:2-48).
+
+``simple_beam_search`` there scores raw frame paths additively without prefix merging, so its best beam is
+always the per-frame argmax path: it equals greedy CTC decoding (pinned in tests/golden).  This
+version computes exactly that with one argmax over the whole [T,V] matrix and one host transfer instead of
+T*beam_width ``.item()`` calls."""
+from __future__ import annotations
+
+import torch
+
+
+def simple_beam_search(log_probs: torch.Tensor, beam_width=5, blank=0):
+    ids = torch.argmax(log_probs, dim=-1).tolist()
+    out, prev = [], None
+    for i in ids:
+        if i != prev and i != blank:
+            out.append(i)
+        prev = i
+    return out
+
+
+def greedy_batch(log_probs: torch.Tensor, blank: int):
+    """[B,T,V] -> list of B id lists (one device argmax + one transfer for the whole batch)."""
+    ids = torch.argmax(log_probs, dim=-1).cpu().tolist()
+    res = []
+    for row in ids:
+        out, prev = [], None
+        for i in row:
+            if i != prev and i != blank:
+                out.append(i)
+            prev = i
+        res.append(out)
+    return res
+
+
+def fast_decode(ids, tokenizer):
+    return "".join(tokenizer.id_to_token[i] for i in ids if i != tokenizer.blank_id and 0 <= i < tokenizer.vocab_size
+                   ).replace("▁", " ").strip()

@@ -1,0 +1,201 @@
+"""MultimodalTrainer with the reference's surface (model/trainer.py:12-252) on the HIP path.
+
+Same constructor arguments and attributes (.visual_encoder .audio_encoder .fusion_module .decoder1 .optimizer
+.device .tokenizer), ``train_epoch(loader) -> float``, ``evaluate(loader) -> (loss, wer)``, ``ctc_decode(ids)``.
+Differences that do not change results:
+  * compute runs in the package precision mode (bf16 perf / fp32 parity) instead of fp16 autocast + GradScaler;
+  * attn_mask1 == attn_mask2 always, so the audio encoder runs ONCE per step by default
+    (``audio_passes=2`` restores the reference's duplicated pass); dropout / LayerDrop / SpecAugment of wav2vec2
+    are not implemented yet, so the two passes would be bit-identical;
+  * the class counts of the contrastive loss are taken from the CPU masks (no host sync);
+  * optional data parallelism: bucketed gradient all-reduce over RCCL overlapped with the audio backward.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .. import _lib as L
+from ..beam_search import fast_decode, greedy_batch
+from ..contrastive import contrastive_loss_with_mask
+from ..optim import AvAdam
+from ..parallel.dp import GradBucketReducer
+
+
+def word_error_rate(refs, hyps) -> float:
+    """jiwer.wer stand-in (jiwer is not installed): total word-level edit distance / total reference words."""
+    errs = words = 0
+    for r, h in zip(refs, hyps):
+        r, h = r.split(), h.split()
+        prev = list(range(len(h) + 1))
+        for i in range(1, len(r) + 1):
+            cur = [i] + [0] * len(h)
+            for j in range(1, len(h) + 1):
+                cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (r[i - 1] != h[j - 1]))
+            prev = cur
+        errs += prev[-1]
+        words += len(r)
+    return errs / max(1, words)
+
+
+class MultimodalTrainer:
+    def __init__(self, visual_encoder, audio_encoder, fusion_module, decoder1, tokenizer, learning_rate=1e-4, device="cuda",
+                 lambda_=0.1, audio_passes: int = 1, reducer: Optional[GradBucketReducer] = None):
+        self.visual_encoder = visual_encoder.to(device)
+        self.audio_encoder = audio_encoder.to(device)
+        self.fusion_module = fusion_module.to(device)
+        self.decoder1 = decoder1.to(device)
+        self.tokenizer = tokenizer
+        self.device = device
+        self.lambda_ = lambda_
+        self.audio_passes = audio_passes
+        self.ctc_loss = nn.CTCLoss(blank=tokenizer.blank_id, zero_infinity=True)       # stays on PyTorch-ROCm
+        self.parameters = (list(self.visual_encoder.parameters()) + list(self.audio_encoder.parameters())
+                           + list(self.fusion_module.parameters()) + list(self.decoder1.parameters()))
+        self.optimizer = AvAdam([
+            {"params": list(self.visual_encoder.parameters()), "lr": learning_rate},
+            {"params": list(self.audio_encoder.parameters()), "lr": 2e-5},
+            {"params": list(self.fusion_module.parameters()), "lr": learning_rate},
+            {"params": list(self.decoder1.parameters()), "lr": learning_rate},
+        ])
+        self.projection_layer = None
+        self.fixed_projection = None        # (weight, bias) to inject instead of a fresh random layer (parity tests)
+        self.reducer = reducer
+        if reducer is not None:
+            self.optimizer.grad_scale = 1.0 / reducer.world
+            self.audio_encoder.model.grad_ready = reducer.reduce_async
+            self.audio_encoder.model.grad_wait = reducer.wait
+            self._head_params = [p for m in (self.decoder1, self.fusion_module) for n, p in m.named_parameters()
+                                 if not n.startswith("cross_attn_visual.")]
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _to_dev(self, batch):
+        dev = self.device
+        nb = lambda t: t.to(dev, non_blocking=True)
+        d = {k: nb(batch[k]) for k in ("audio", "mask1", "mask2", "text1", "text2", "text1_lengths", "text2_lengths")}
+        # [B,T,1,H,W] -> [B,1,T,H,W]: with one channel the two layouts are byte-identical => a view
+        d["lip1"] = nb(batch["lip1"]).permute(0, 2, 1, 3, 4)
+        d["lip2"] = nb(batch["lip2"]).permute(0, 2, 1, 3, 4)
+        return d
+
+    def _mask_ds(self, mask, T_enc):
+        B, Tin = mask.shape
+        out = torch.empty((B, T_enc), dtype=torch.long, device=mask.device)
+        L.check(L.lib().av_mask_downsample(ops.ptr(mask.contiguous()), ops.ptr(out), B, Tin, T_enc, ops.stream()), "av_mask_downsample")
+        return out
+
+    @staticmethod
+    def _class_counts(mask_cpu: torch.Tensor, T_enc: int):
+        """(#1, #2, #0) of the down-sampled mask, computed on the host copy of the batch (no device sync)."""
+        Tin = mask_cpu.shape[1]
+        scale = torch.tensor(Tin / T_enc, dtype=torch.float32)
+        idx = torch.floor(torch.arange(T_enc, dtype=torch.float32) * scale).long().clamp_(max=Tin - 1)
+        c = torch.bincount(mask_cpu[:, idx].reshape(-1).clamp(0, 3), minlength=4).tolist()
+        return (c[1], c[2], c[0])
+
+    def forward_losses(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """model/trainer.py:66-119 for one batch; everything stays on the device."""
+        d = self._to_dev(batch)
+        vf1 = self.visual_encoder(d["lip1"])
+        vf2 = self.visual_encoder(d["lip2"])
+        attn1 = d["mask1"] != 3
+        a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1)
+        if self.audio_passes == 2:
+            a2, mid2 = self.audio_encoder(d["audio"], attention_mask=(d["mask2"] != 3))
+        else:
+            a2, mid2 = a1, mid1
+        T_enc, D = a1.shape[1], a1.shape[2]
+        m1 = self._mask_ds(d["mask1"], T_enc)
+        m2 = self._mask_ds(d["mask2"], T_enc)
+        out = {}
+        if self.lambda_ != 0:
+            if self.projection_layer is None:
+                self.projection_layer = nn.Linear(D, 128).to(self.device)          # model/trainer.py:105-106
+                if self.fixed_projection is not None:
+                    with torch.no_grad():
+                        self.projection_layer.weight.copy_(self.fixed_projection[0]); self.projection_layer.bias.copy_(self.fixed_projection[1])
+            c1 = contrastive_loss_with_mask(mid1, m1.reshape(-1), self.projection_layer, counts=self._class_counts(batch["mask1"], T_enc))
+            c2 = contrastive_loss_with_mask(mid2, m2.reshape(-1), self.projection_layer, counts=self._class_counts(batch["mask2"], T_enc))
+        else:
+            c1 = c2 = torch.zeros((), device=a1.device)
+        f1, il1 = self.fusion_module(vf1, a1, mask=m1)
+        f2, il2 = self.fusion_module(vf2, a2, mask=m2)
+        lp1 = self.decoder1(f1)
+        lp2 = self.decoder1(f2)
+        l1 = self.ctc_loss(lp1.transpose(0, 1), d["text1"], il1, d["text1_lengths"])
+        l2 = self.ctc_loss(lp2.transpose(0, 1), d["text2"], il2, d["text2_lengths"])
+        total = (l1 + l2) / 2 + self.lambda_ * (c1 + c2) / 2
+        out.update(visual_feat1=vf1, visual_feat2=vf2, audio_last=a1, audio_mid=mid1, fused1=f1, fused2=f2, input_lengths1=il1,
+                   input_lengths2=il2, log_probs1=lp1, log_probs2=lp2, loss1=l1, loss2=l2, contrast1=c1, contrast2=c2, total=total)
+        return out
+
+    def train_step(self, batch) -> Dict[str, torch.Tensor]:
+        """zero_grad -> forward -> backward (-> bucketed all-reduce) -> Adam; no host sync."""
+        self.optimizer.zero_grad(set_to_none=True)
+        out = self.forward_losses(batch)
+        out["total"].backward()
+        if self.reducer is not None:
+            # wav2vec2 layer buckets were reduced inside its backward (overlapped); the decoder + fusion bucket goes now
+            hp = [p for p in self._head_params if p.grad is not None]
+            views = self.reducer.reduce_async([p.grad for p in hp])
+            self.reducer.wait()
+            for p, v in zip(hp, views):
+                p.grad = v
+        self.optimizer.step()
+        return out
+
+    def train_epoch(self, dataloader):
+        self.visual_encoder.train(); self.audio_encoder.train(); self.fusion_module.train(); self.decoder1.train()
+        self.projection_layer = None
+        total_loss = 0.0
+        for batch_idx, batch in enumerate(dataloader):
+            try:
+                out = self.train_step(batch)
+                total_loss += out["total"].item()
+                if batch_idx % 100 == 0:
+                    print(f"[Batch {batch_idx}] CTC1: {out['loss1'].item():.4f}, CTC2: {out['loss2'].item():.4f}, "
+                          f"Contrast1: {float(out['contrast1']):.4f}, Contrast2: {float(out['contrast2']):.4f}, "
+                          f"Total: {out['total'].item():.4f}", flush=True)
+            except Exception as e:       # model/trainer.py:162-164: skip the batch, keep going
+                print(f"Error at batch {batch_idx}: {e}", flush=True)
+                continue
+        return total_loss / max(1, len(dataloader))
+
+    def ctc_decode(self, pred_ids):
+        """model/trainer.py:168-177 (prev is NOT reset on blank — kept as in the reference's debug helper)."""
+        result, prev = [], None
+        for idx in pred_ids:
+            if idx == self.tokenizer.blank_id:
+                continue
+            if idx != prev:
+                result.append(idx)
+            prev = idx
+        return result
+
+    @torch.no_grad()
+    def evaluate(self, dataloader):
+        self.visual_encoder.eval(); self.audio_encoder.eval(); self.fusion_module.eval(); self.decoder1.eval()
+        refs1, hyps1, refs2, hyps2 = [], [], [], []
+        total_loss = 0.0
+        lam, self.lambda_ = self.lambda_, 0.0
+        try:
+            for batch in dataloader:
+                out = self.forward_losses(batch)
+                total_loss += (out["loss1"].item() + out["loss2"].item()) / 2
+                for spk, lp, refs, hyps in (("1", out["log_probs1"], refs1, hyps1), ("2", out["log_probs2"], refs2, hyps2)):
+                    ids = greedy_batch(lp, self.tokenizer.blank_id)       # == simple_beam_search best beam
+                    txt, tl = batch["text" + spk], batch["text" + spk + "_lengths"]
+                    for i, seq in enumerate(ids):
+                        hyps.append(fast_decode(seq, self.tokenizer))
+                        refs.append(self.tokenizer.decode(txt[i][: int(tl[i])].tolist()))
+        finally:
+            self.lambda_ = lam
+        wer1, wer2 = word_error_rate(refs1, hyps1), word_error_rate(refs2, hyps2)
+        avg_wer = (wer1 + wer2) / 2
+        avg_loss = total_loss / max(1, len(dataloader))
+        print(f"[Eval] WER1: {wer1:.3f}, WER2: {wer2:.3f}, Avg: {avg_wer:.3f}, Loss: {avg_loss:.4f}")
+        self.last_decoded = (hyps1, hyps2)
+        return avg_loss, avg_wer

@@ -100,6 +100,9 @@ class Wav2Vec2ModelHIP(nn.Module):
         build_param_tree(self, param_shapes(cfg))
         self._cache = _Cache()
         self._names = [n for n, _ in self.named_parameters()]
+        # data-parallel hooks (parallel/dp.py): per-layer gradient bucket -> async all-reduce, joined at the end of backward
+        self.grad_ready = None
+        self.grad_wait = None
 
     # ---- parameter access ------------------------------------------------------------------------------------
     def P(self, name: str) -> Tensor:
@@ -315,6 +318,12 @@ class Wav2Vec2ModelHIP(nn.Module):
             else:
                 dh = r
             ctx["saved"][li] = None        # free as we go
+            if tr and self.grad_ready is not None:                  # bucket = this layer's 16 tensors, reduced on a side stream
+                keys = [k for k in grads if k.startswith(p)]
+                for k, v in zip(keys, self.grad_ready([grads[k] for k in keys])):
+                    grads[k] = v
+        if self.grad_wait is not None:
+            self.grad_wait()
         return grads
 
 

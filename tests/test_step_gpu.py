@@ -1,0 +1,130 @@
+"""Whole training step on the HIP path vs the fixtures captured FROM THE REFERENCE (tests/golden/*.npz):
+logits, CTC / contrastive losses, input_lengths, decoded ids, gradients, post-Adam deltas, BN running statistics."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build(cfg, precision):
+    init = pkg("utils.init"); enc = pkg("model.encoder"); fm = pkg("model.fusion_module"); dm = pkg("model.decoder")
+    tr = pkg("model.trainer"); tok = pkg("utils.tokenizer")
+    pkg("precision").set_precision(precision)
+    ve = enc.VisualEncoder(); ve.load_state_dict(init.visual_state_dict())
+    for p in ve.parameters():
+        p.requires_grad = False                                        # main.py:100-103
+    ae = enc.AudioEncoder(dict(cfg), freeze=True); ae.load_state_dict(init.w2v2_state_dict(cfg))
+    for n, p in ae.model.named_parameters():                           # main.py:26-31
+        p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
+    fu = fm.CrossAttentionFusion(512, cfg["hidden_size"], 512); fu.load_state_dict(init.fusion_state_dict(512, cfg["hidden_size"], 512))
+    de = dm.CTCDecoder(1024, 800, 3); de.load_state_dict(init.decoder_state_dict(1024, 800))
+    t = tr.MultimodalTrainer(ve, ae, fu, de, tok.SyntheticTokenizer(800), learning_rate=1e-4, device="cuda", lambda_=0.1)
+    t.fixed_projection = init.projection_params(cfg["hidden_size"])
+    return t
+
+
+def maxdiff(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+@pytest.mark.parametrize("name,cfg_name", [("tiny", "W2V2_TINY"), ("tiny_ragged", "W2V2_TINY"), ("c1", "W2V2_LARGE")])
+def test_step_fp32_vs_reference_fixture(name, cfg_name):
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    init = pkg("utils.init"); synth = pkg("dataset.synthetic")
+    cfg = getattr(init, cfg_name)
+    t = build(cfg, "fp32")
+    batch = synth.make_batch(int(fx["batch"]), float(fx["seconds"]), seed=int(fx["seed_batch"]), ragged=bool(fx["ragged"]))
+    tol = 1e-3                                                         # BASELINE north_star: 1e-3 fp32
+    # ---- eval (BN running statistics) ----
+    ev_loss, _ = t.evaluate([batch])
+    t.visual_encoder.eval()
+    with torch.no_grad():
+        o = t.forward_losses(batch)
+    assert maxdiff(o["visual_feat1"].cpu(), fx["eval_visual1"]) < tol * 10      # features are O(10); relative 1e-4
+    assert maxdiff(o["audio_last"].cpu().numpy()[..., ::8], fx["eval_audio_last"]) < tol
+    assert maxdiff(o["fused1"].cpu(), fx["eval_fused1"]) < tol
+    assert maxdiff(o["log_probs1"].cpu(), fx["eval_log_probs1"]) < tol
+    assert maxdiff(o["log_probs2"].cpu(), fx["eval_log_probs2"]) < tol
+    assert np.array_equal(o["input_lengths1"].cpu().numpy(), fx["eval_input_lengths1"])
+    assert np.array_equal(o["input_lengths2"].cpu().numpy(), fx["eval_input_lengths2"])
+    assert abs(ev_loss - float(fx["eval_loss"])) < tol * 5
+    hyp1, hyp2 = t.last_decoded
+    bs = pkg("beam_search")
+    dec = []
+    for i in range(len(hyp1)):
+        dec += [bs.simple_beam_search(o["log_probs1"][i], 5, 3), bs.simple_beam_search(o["log_probs2"][i], 5, 3)]
+    want = [[int(x) for x in s.split(",")] if s else [] for s in fx["eval_decoded"].tolist()]
+    assert dec == want, "decoded token ids differ from the reference's beam search"
+    # ---- one training step ----
+    before = {n: p.detach().clone() for m, mod in (("audio", t.audio_encoder), ("fusion", t.fusion_module), ("decoder", t.decoder1))
+              for n, p in ((m + "." + k, v) for k, v in mod.named_parameters())}
+    t.visual_encoder.train(); t.audio_encoder.train(); t.fusion_module.train(); t.decoder1.train()
+    t.projection_layer = None
+    out = t.train_step(batch)
+    assert maxdiff(out["visual_feat1"].detach().cpu(), fx["train_visual1"]) < tol * 10
+    assert maxdiff(out["visual_feat2"].detach().cpu(), fx["train_visual2"]) < tol * 10
+    assert maxdiff(out["audio_last"].detach().cpu().numpy()[..., ::8], fx["train_audio_last"]) < tol
+    assert maxdiff(out["audio_mid"].detach().cpu().numpy()[..., ::8], fx["train_audio_mid"]) < tol
+    assert maxdiff(out["fused1"].detach().cpu(), fx["train_fused1"]) < tol
+    assert maxdiff(out["log_probs1"].detach().cpu(), fx["train_log_probs1"]) < tol
+    assert maxdiff(out["log_probs2"].detach().cpu(), fx["train_log_probs2"]) < tol
+    for k in ("loss1", "loss2", "contrast1", "contrast2", "total"):
+        assert abs(float(out[k]) - float(fx["train_" + k])) < tol * 5, k
+    assert np.array_equal(out["input_lengths1"].cpu().numpy(), fx["train_input_lengths1"])
+    # gradients: None-ness, norms and slices
+    mods = {"audio": t.audio_encoder, "fusion": t.fusion_module, "decoder": t.decoder1}
+    none = sorted(m + "." + k for m, mod in mods.items() for k, p in mod.named_parameters() if p.grad is None)
+    assert none == fx["none_grads"].tolist()
+    worst = 0.0
+    for key in fx.files:
+        if key.startswith("gradnorm/"):
+            m, k = key[9:].split(".", 1)
+            g = dict(mods[m].named_parameters())[k].grad
+            ref = float(fx[key])
+            if "k_proj.bias" in k:
+                continue
+            rel = abs(float(g.norm()) - ref) / (ref + 1e-12)
+            worst = max(worst, rel)
+            assert rel < 2e-3, (key, rel)
+        if key.startswith("gradslice/"):
+            m, k = key[10:].split(".", 1)
+            g = dict(mods[m].named_parameters())[k].grad.reshape(-1)
+            sl = g[:: max(1, g.numel() // 2048)][:2048].cpu().numpy()
+            assert maxdiff(sl, fx[key]) < 2e-3 * max(1e-6, float(np.abs(fx[key]).max())) + 1e-7, key
+    print("worst grad-norm rel err", worst)
+    # post-Adam parameter deltas: |delta| <= lr and sign-exact where the gradient is not tiny
+    for key in fx.files:
+        if key.startswith("adamdelta/"):
+            m, k = key[10:].split(".", 1)
+            pnow = dict(mods[m].named_parameters())[k].detach()
+            d = (pnow - before[m + "." + k]).reshape(-1)
+            sl = d[:: max(1, d.numel() // 2048)][:2048].cpu().numpy()
+            ref = fx[key]
+            close = np.abs(sl - ref) < 2e-6
+            assert close.mean() > 0.98, (key, close.mean())
+    # BatchNorm running statistics after the step (two updates: lip1 call, lip2 call)
+    vs = t.visual_encoder.state_dict()
+    for key in fx.files:
+        if key.startswith("bn_after/"):
+            assert maxdiff(vs[key[9:]].cpu(), fx[key]) < 2e-4, key
+    assert int(vs["frontend3D.1.num_batches_tracked"]) == int(fx["bn_num_batches_tracked"])
+
+
+def test_step_bf16_reported_error():
+    """Perf mode: same step in bf16; the error against the reference fixture is measured and bounded loosely."""
+    fx = np.load(os.path.join(GOLD, "tiny.npz"))
+    init = pkg("utils.init"); synth = pkg("dataset.synthetic")
+    t = build(init.W2V2_TINY, "bf16")
+    batch = synth.make_batch(int(fx["batch"]), float(fx["seconds"]), seed=int(fx["seed_batch"]), ragged=False)
+    t.visual_encoder.train()
+    out = t.train_step(batch)
+    e_lp = maxdiff(out["log_probs1"].detach().cpu(), fx["train_log_probs1"])
+    e_loss = abs(float(out["total"]) - float(fx["train_total"]))
+    print(f"bf16 step: max|dlogp| = {e_lp:.4f}, |dloss| = {e_loss:.4f} (loss {float(fx['train_total']):.3f})")
+    assert e_lp < 0.5 and e_loss < 0.5
