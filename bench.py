@@ -1,0 +1,189 @@
+"""Benchmark of the hot path: utterances/sec of the full audio-visual CTC training step (fwd + bwd + Adam).
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload at N=1 = BASELINE.json configs[1]: batch 32 x 4 s clips (64 000 samples @16 kHz + 100 lip frames 96x96 per
+speaker), wav2vec2-large architecture, random-init weights, synthetic data, bf16 MFMA compute with fp32 master
+weights; N > 1 keeps the per-GPU batch (weak scaling) and all-reduces the 63.8 M trainable gradients over RCCL.
+Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "multimodal-av-model_amd"
+
+
+def imp(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+def flops_per_utt(cfg, T_audio, T_v, audio_passes):
+    """SURVEY §8(d) algorithmic FLOPs (2*MAC) per utterance, fwd + needed bwd, for the variant executed."""
+    L = T_audio
+    conv = 0.0
+    cin = 1
+    for k, s, c in zip(cfg["conv_kernel"], cfg["conv_stride"], cfg["conv_dim"]):
+        L = (L - k) // s + 1
+        conv += 2.0 * k * cin * c * L
+        cin = c
+    T = L
+    H, I, nl = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    lin = (8.0 * H * H + 4.0 * H * I) * T
+    att = 4.0 * T * T * H
+    kp, G = cfg["num_conv_pos_embeddings"], cfg["num_conv_pos_embedding_groups"]
+    A = conv + 2.0 * cin * H * T + 2.0 * kp * (H // G) * H * T + nl * (lin + att)
+    Ab = 14 * (lin + 2 * att) + 4 * (2 * lin + 2 * att)
+    V = 695.2e6 * T_v
+    F = T_v * (2 * 512 ** 2 + 2 * 1024 * 512 + 8 * 512 ** 2 + 2 * 512 ** 2 + 2 * 4 * 512 * (1024 + 1536) * 2 + 2 * 1024 * 800) + 4.0 * T_v ** 2 * 512
+    return audio_passes * (A + Ab) + 2 * V + 2 * F + 2 * 2 * F
+
+
+def cpu_baseline(cfg, seconds):
+    """The CPU oracle (checked against the reference in the build container) timed on this box's host cores."""
+    from oracle import av_oracle as O
+    init = imp("utils.init"); synth = imp("dataset.synthetic")
+    B = 2
+    batch = synth.make_batch(B, seconds, seed=42)
+    sds = [init.visual_state_dict(), init.w2v2_state_dict(cfg), init.fusion_state_dict(512, cfg["hidden_size"], 512),
+           init.decoder_state_dict(1024, 800)]
+    proj = init.projection_params(cfg["hidden_size"])
+    st = {}
+    O.train_step(*sds, cfg, batch, proj, st, dedup_audio=False)         # warm-up
+    t0 = time.time()
+    n = 2
+    for _ in range(n):
+        O.train_step(*sds, cfg, batch, proj, st, dedup_audio=False)     # as the reference executes it: two audio passes
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"B={B} x {seconds:g} s clips, {n} fp32 steps after 1 warm-up, two audio passes as the reference runs it"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[1]: 32)")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--audio-passes", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--lambda", dest="lambda_", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    init = imp("utils.init"); synth = imp("dataset.synthetic"); enc = imp("model.encoder"); fm = imp("model.fusion_module")
+    dm = imp("model.decoder"); tr = imp("model.trainer"); tok = imp("utils.tokenizer"); dp = imp("parallel.dp"); ops = imp("ops")
+    L = imp("_lib")
+    imp("precision").set_precision(args.precision)
+    cfg = init.W2V2_LARGE
+
+    ve = enc.VisualEncoder(); ve.load_state_dict(init.visual_state_dict())
+    for p in ve.parameters():
+        p.requires_grad = False
+    ae = enc.AudioEncoder(dict(cfg), freeze=True)
+    for n, p in ae.model.named_parameters():
+        p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
+    fu = fm.CrossAttentionFusion(512, cfg["hidden_size"], 512); fu.load_state_dict(init.fusion_state_dict(512, cfg["hidden_size"], 512))
+    de = dm.CTCDecoder(1024, 800, 3); de.load_state_dict(init.decoder_state_dict(1024, 800))
+    reducer = dp.GradBucketReducer() if world > 1 else None
+    t = tr.MultimodalTrainer(ve, ae, fu, de, tok.SyntheticTokenizer(800), learning_rate=1e-4, device=dev, lambda_=args.lambda_,
+                             audio_passes=args.audio_passes, reducer=reducer)
+    t.fixed_projection = init.projection_params(cfg["hidden_size"])      # identical on every rank (SURVEY §8e caveat 4)
+    t.visual_encoder.train(); t.audio_encoder.train(); t.fusion_module.train(); t.decoder1.train()
+
+    cpu_batch = synth.make_batch(args.batch, args.seconds, seed=42 + rank)
+    T_audio = cpu_batch["audio"].shape[1]
+    T_v = cpu_batch["lip1"].shape[1]
+    T_enc = int(imp("model.w2v2").conv_out_lengths(cfg, T_audio))
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+    batch["_counts1"] = t._class_counts(cpu_batch["mask1"], T_enc)
+    batch["_counts2"] = t._class_counts(cpu_batch["mask2"], T_enc)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = t.train_step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    if not args.no_probe and rank == 0:
+        ops.GemmProbe.start(L.AV_BF16 if args.precision == "bf16" else L.AV_F32, L.A_ROWMAJOR, L.B_NK, True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = t.train_step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    probe = ops.GemmProbe.stop() if (not args.no_probe and rank == 0) else None
+    loss = float(out["total"])
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+
+    if rank == 0:
+        ms = 1000.0 * dt / args.steps
+        utt_s = args.batch * world / (dt / args.steps)
+        fl = flops_per_utt(cfg, T_audio, T_v, args.audio_passes)
+        peak = 2500.0 if args.precision == "bf16" else 157.3
+        roof = None
+        if probe and probe["records"]:
+            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in probe["records"])
+            tot_fl = sum(f for _, _, f in probe["records"])
+            n = len(probe["records"])
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": f"gemm_kernel<{args.precision},128,rowmajor,NK> (nn.Linear / strided-conv forward GEMMs)",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "launches_per_step": n // args.steps, "avg_launch_us": round(1000.0 * tot_ms / n, 2),
+                    "algorithmic_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
+        res = {"metric": "utterances/sec (4 s clip, 25 fps 96x96 lip), full training step", "value": round(utt_s, 3),
+               "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": f"configs[1]: batch {args.batch}/GPU x {args.seconds:g} s (T_audio {T_audio}, T_enc {T_enc}, "
+                                      f"{T_v} lip frames 96x96 x 2 speakers), wav2vec2-large + ResNet-18 + fusion BiLSTM + CTC, "
+                                      "fwd+bwd+Adam, random-init weights",
+                          "global_batch": args.batch * world, "parallelism": f"dp{world}", "audio_passes": args.audio_passes,
+                          "lambda_contrastive": args.lambda_, "final_loss": round(loss, 4),
+                          "algorithmic_gflop_per_utt": round(fl / 1e9, 1),
+                          "step_tflops": round(fl * utt_s / 1e12, 1), "step_frac_of_mfma_peak": round(fl * utt_s / 1e12 / peak, 4)},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, args.seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,7 +134,7 @@ int av_scatter_rows(const float* src, const long long* idx, float* out, long lon
 /* ---- lip-frame encoder glue (model/encoder.py:6-75): train-mode BatchNorm, PReLU, pooling; NHWC ------------ */
 int av_bn_finalize(const float* partial, int nblk, long long count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
-                   float* shift, int C, void* stream);
+                   float* shift, int C, double* ws /* 2C doubles */, void* stream);
 int av_bn_act(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
               const float* rshift, const float* slope, void* out, int dtype, long long n, int C, void* stream);
 int av_bn_prelu_maxpool(const void* x, const float* scale, const float* shift, const float* slope, void* out, int dtype,

@@ -10,20 +10,31 @@
 
 namespace {
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, double count, const float* __restrict__ gamma,
+// stage 1: column sums of the [nblk][2C] partial matrix in double (coalesced over channels, f64 atomics to ws[2C])
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ part, int nblk, int C2, double* __restrict__ ws) {
+    __shared__ double red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * 512;
+    int r1 = r0 + 512;
+    if (r1 > nblk) r1 = nblk;
+    double s = 0.0;
+    if (c < C2)
+        for (int r = r0 + ry; r < r1; r += 4) s += (double)part[(long long)r * C2 + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C2) atomicAdd(ws + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                    float eps, int training, float* __restrict__ scale, float* __restrict__ shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float sc, sh;
     if (training) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < nblk; ++b) {
-            s += (double)part[(long long)b * 2 * C + c];
-            q += (double)part[(long long)b * 2 * C + C + c];
-        }
-        const double mean = s / count;
-        double var = q / count - mean * mean;
+        const double mean = ws[c] / count;
+        double var = ws[C + c] / count - mean * mean;
         if (var < 0.0) var = 0.0;
         sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
         sh = beta[c] - (float)mean * sc;
@@ -106,10 +117,17 @@ inline int ew_grid(long long n) {
 }  // namespace
 
 extern "C" int av_bn_finalize(const float* partial, int nblk, long long count, const float* gamma, const float* beta, float* running_mean,
-                              float* running_var, float momentum, float eps, int training, float* scale, float* shift, int C, void* stream) {
+                              float* running_var, float momentum, float eps, int training, float* scale, float* shift, int C, double* ws,
+                              void* stream) {
     AV_CHECK(gamma && beta && scale && shift && C > 0, "av_bn_finalize: null pointer");
-    AV_CHECK(training ? (partial != nullptr && nblk > 0 && count > 0) : (running_mean && running_var), "av_bn_finalize: missing statistics input");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, (double)count, gamma, beta,
+    AV_CHECK(training ? (partial != nullptr && nblk > 0 && count > 0 && ws != nullptr) : (running_mean && running_var), "av_bn_finalize: missing statistics input");
+    hipStream_t st = (hipStream_t)stream;
+    if (training) {
+        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { av_set_error("av_bn_finalize: memset failed"); return AV_ERR_LAUNCH; }
+        hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * C + 63) / 64, (nblk + 511) / 512), dim3(256), 0, st, partial, nblk, 2 * C, ws);
+        AV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ws, (double)count, gamma, beta,
                        running_mean, running_var, momentum, eps, training, scale, shift, C);
     AV_LAUNCH_CHECK();
     return AV_OK;

@@ -127,9 +127,10 @@ class VisualEncoder(nn.Module):
         C = bn.num_features
         dev = bn.weight.device
         scale = torch.empty(C, dtype=torch.float32, device=dev); shift = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(2 * C, dtype=torch.float64, device=dev) if training else None
         L.check(L.lib().av_bn_finalize(ops.ptr(stats), nblk, count, ops.ptr(bn.weight.data), ops.ptr(bn.bias.data),
                                        ops.ptr(bn.running_mean), ops.ptr(bn.running_var), float(bn.momentum), float(bn.eps),
-                                       int(training), ops.ptr(scale), ops.ptr(shift), C, ops.stream()), "av_bn_finalize")
+                                       int(training), ops.ptr(scale), ops.ptr(shift), C, ops.ptr(ws), ops.stream()), "av_bn_finalize")
         if training:
             bn.num_batches_tracked += 1
         return scale, shift

@@ -89,7 +89,9 @@ class MultimodalTrainer:
 
     @staticmethod
     def _class_counts(mask_cpu: torch.Tensor, T_enc: int):
-        """(#1, #2, #0) of the down-sampled mask, computed on the host copy of the batch (no device sync)."""
+        """(#1, #2, #0) of the down-sampled mask, computed on the host copy of the batch (no device sync when the
+        batch arrives from a DataLoader; a device-resident batch should carry precomputed ``_counts1/_counts2``)."""
+        mask_cpu = mask_cpu.cpu()
         Tin = mask_cpu.shape[1]
         scale = torch.tensor(Tin / T_enc, dtype=torch.float32)
         idx = torch.floor(torch.arange(T_enc, dtype=torch.float32) * scale).long().clamp_(max=Tin - 1)
@@ -117,8 +119,10 @@ class MultimodalTrainer:
                 if self.fixed_projection is not None:
                     with torch.no_grad():
                         self.projection_layer.weight.copy_(self.fixed_projection[0]); self.projection_layer.bias.copy_(self.fixed_projection[1])
-            c1 = contrastive_loss_with_mask(mid1, m1.reshape(-1), self.projection_layer, counts=self._class_counts(batch["mask1"], T_enc))
-            c2 = contrastive_loss_with_mask(mid2, m2.reshape(-1), self.projection_layer, counts=self._class_counts(batch["mask2"], T_enc))
+            k1 = batch.get("_counts1") or self._class_counts(batch["mask1"], T_enc)
+            k2 = batch.get("_counts2") or self._class_counts(batch["mask2"], T_enc)
+            c1 = contrastive_loss_with_mask(mid1, m1.reshape(-1), self.projection_layer, counts=k1)
+            c2 = contrastive_loss_with_mask(mid2, m2.reshape(-1), self.projection_layer, counts=k2)
         else:
             c1 = c2 = torch.zeros((), device=a1.device)
         f1, il1 = self.fusion_module(vf1, a1, mask=m1)

@@ -40,6 +40,20 @@ def _req(t: Tensor, name: str):
         raise RuntimeError(f"{name}: tensor must live on the GPU (no CPU fallback in libavhip)")
 
 
+class GemmProbe:
+    """Optional live timing of ONE av_gemm instantiation with events on the launch stream (bench.py roofline leg)."""
+    active = None            # dict(key=(in_dtype, a_mode, b_mode, wide), records=[(start, end, flops)])
+
+    @classmethod
+    def start(cls, in_dtype: int, a_mode: int, b_mode: int, wide: bool):
+        cls.active = dict(key=(in_dtype, a_mode, b_mode, wide), records=[])
+
+    @classmethod
+    def stop(cls):
+        a, cls.active = cls.active, None
+        return a
+
+
 def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
          a_mode: int = L.A_ROWMAJOR, b_mode: int = L.B_NK, bias: Optional[Tensor] = None, act: int = L.ACT_NONE,
          R: Optional[Tensor] = None, ldr: int = 0, aux: Optional[Tensor] = None, C2: Optional[Tensor] = None,
@@ -72,6 +86,14 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
     if conv:
         for k, v in conv.items():
             setattr(a, k, v)
+    pr = GemmProbe.active
+    if pr is not None and pr["key"] == (a.in_dtype, a_mode, b_mode, N > 64):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().av_gemm(C.byref(a), stream()), "av_gemm")
+        e1.record()
+        pr["records"].append((e0, e1, 2.0 * M * N * K * batch))
+        return C_
     L.check(L.lib().av_gemm(C.byref(a), stream()), "av_gemm")
     return C_
 
