@@ -69,6 +69,8 @@ typedef struct av_gemm_args {
     long long oA, oB, oC;
 } av_gemm_args;
 int av_gemm(const av_gemm_args* args, void* stream);
+/* out[C][Rpad] = in[R][C]^T (zero-filled for r >= R): brings dX / dW products to the fast K-contiguous form */
+int av_transpose(const void* in, int idt, void* out, int odt, int R, int C, long long ldi, int Rpad, void* stream);
 
 /* ---- row kernels (one wavefront per row, shuffle reductions) ------------------------------------------- */
 /* nn.LayerNorm over the last dim (hf:297,431,638,644,791), eps 1e-5, optional exact-erf GELU (hf:298).

@@ -38,6 +38,7 @@ SIGNATURES = {
     "av_last_error": [],
     "av_version": [],
     "av_gemm": [C.POINTER(GemmArgs), vp],
+    "av_transpose": [vp, i32, vp, i32, i32, i32, ll, i32, vp],
     "av_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, ll, i32, f32, i32, vp],
     "av_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp],
     "av_log_softmax_fwd": [vp, i32, vp, ll, i32, vp],

@@ -368,6 +368,8 @@ template <typename T> bool vec_ok2(const void* base, long long ld, long long s1,
 
 }  // namespace
 
+int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st);   // gemm_fast.hip; -1 = not eligible
+
 extern "C" int av_gemm(const av_gemm_args* a, void* stream) {
     AV_CHECK(a != nullptr, "av_gemm: null args");
     const av_gemm_args& p = *a;
@@ -391,6 +393,10 @@ extern "C" int av_gemm(const av_gemm_args* a, void* stream) {
         AV_CHECK(p.cOh > 0 && p.cOw > 0 && p.cT > 0 && p.M % (p.cOh * p.cOw * p.cT) == 0, "av_gemm conv3d: bad M=%d", p.M);
     }
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int fr = av_gemm_fast_try(p, st);
+        if (fr >= 0) return fr;
+    }
     const bool wide = p.N > 64;
     if (p.in_dtype == AV_F32) {
         const bool av = vec_ok2<float>(p.A, p.lda, p.sA, p.oA), bv = vec_ok2<float>(p.B, p.ldb, p.sB, p.oB);

@@ -1,0 +1,250 @@
+// Fast path of av_gemm for the dominant shape class: bf16, C = epilogue(alpha * A[M,K] x B[N,K]^T), both operands
+// K-contiguous (nn.Linear forward; dX and dW are brought to this form with cached W^T / one HBM-bound transpose).
+//
+//   * 128 x 128 x 64 block tile, 256 threads = 4 wavefronts (2 x 2), 64 x 64 per wave = 4 x 4 MFMA 16x16x32 tiles;
+//   * global -> LDS with direct `global_load_lds_dwordx4` (no VGPR staging): one wave instruction fills 8 tile rows
+//     of 128 B; two LDS buffers, the loads of K-tile t+1 are issued BEFORE the MFMA phase of tile t and retired by
+//     the single barrier per K-tile (guide T3/T4 "minimum 2-phase" structure);
+//   * LDS rows are 128 B (no padding is possible with LDS-DMA), so the 16-B chunk index is XOR-swizzled with
+//     (row & 7): applied on the per-lane SOURCE address when staging and on the ds_read_b128 fragment address
+//     (both-sides rule) -> conflict-free fragment reads;
+//   * XCD-aware bijective remap of blockIdx so that tiles sharing an A panel run on one XCD (private L2);
+//   * epilogue through an fp32 LDS image so that bias / GELU / gelu' x aux / residual / C2 and the stores are
+//     16-32 B per lane and row-contiguous.
+#include "av_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
+constexpr int TILE_B = BM * BK * 2;       // 16 KiB per operand per buffer
+constexpr int CLD = 132;                  // fp32 epilogue image leading dimension (floats)
+constexpr int LDS_BYTES = BM * CLD * 4;   // 67 584 B >= 4 * TILE_B
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile,
+                                           int w, int lane) {
+    const int sub = lane >> 3, pch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (w * 4 + i) * 8 + sub;
+        int gr = row0 + row;
+        if (gr > nrows - 1) gr = nrows - 1;                      // clamped rows are computed but never stored
+        const bf16_t* src = base + (long long)gr * ld + k0 + ((pch ^ sub) << 3);
+        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 4 + i) * 1024));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+    }
+}
+
+struct FastFlags { int c_vec, r_vec, aux_vec; };
+
+__global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 15, g = lane >> 4;
+
+    // XCD-aware bijective remap: consecutive tile ids (sharing an A panel) land on the same XCD
+    const int nwg = nbM * nbN;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    const int mb = bid / nbN, nb = bid - mb * nbN;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int z = blockIdx.z;
+    const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
+    const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
+    const bf16_t* A = (const bf16_t*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
+    const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage_tile(A, p.lda, m0, p.M, 0, smem, w, lane);
+    stage_tile(B, p.ldb, n0, p.N, 0, smem + TILE_B, w, lane);
+    __syncthreads();
+
+    // per-lane fragment addressing: row = base + 16*t + r (row & 7 == r & 7), chunk = 4*ks + g
+    const int sw = r & 7;
+    const char* a_base = smem + (wm * 64 + r) * 128;
+    const char* b_base = smem + TILE_B + (wn * 64 + r) * 128;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            char* nxt = smem + (cur ^ 1) * 2 * TILE_B;
+            stage_tile(A, p.lda, m0, p.M, (kt + 1) * BK, nxt, w, lane);
+            stage_tile(B, p.ldb, n0, p.N, (kt + 1) * BK, nxt + TILE_B, w, lane);
+        }
+        const char* ab = a_base + cur * 2 * TILE_B;
+        const char* bb = b_base + cur * 2 * TILE_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int choff = ((ks * 4 + g) ^ sw) << 4;
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(ab + i * 16 * 128 + choff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(bb + j * 16 * 128 + choff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: accumulators -> fp32 LDS image -> row-contiguous vector stores ----------------
+    float* cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                cs[(wm * 64 + i * 16 + 4 * g + e) * CLD + wn * 64 + j * 16 + r] = acc[i][j][e] * p.alpha;
+    __syncthreads();
+
+    const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
+    const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
+    const float* bias = p.bias ? p.bias + (long long)zi * p.sBias : nullptr;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int id = it * NT + tid;
+        const int row = id >> 4, cc = (id & 15) * 8;
+        const int gm = m0 + row, gn = n0 + cc;
+        if (gm >= p.M || gn >= p.N) continue;
+        float v[8];
+        const f32x4 v0 = *(const f32x4*)(cs + row * CLD + cc), v1 = *(const f32x4*)(cs + row * CLD + cc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+        const bool full = gn + 8 <= p.N;
+        const long long off = cbase + (long long)gm * p.ldc + gn;
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (full || gn + e < p.N) v[e] += bias[gn + e];
+        }
+        if (p.C2) {
+            if (full && fl.c_vec) {
+                if (p.out_dtype == AV_BF16) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    *(bf16x8*)((bf16_t*)p.C2 + off) = o;
+                } else {
+                    *(f32x4*)((float*)p.C2 + off) = f32x4{v[0], v[1], v[2], v[3]};
+                    *(f32x4*)((float*)p.C2 + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C2, off + e, p.out_dtype, v[e]);
+            }
+        }
+        if (p.act == AV_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (p.act == AV_ACT_MUL_GELU_GRAD) {
+            if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
+                const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)u[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_f(ld_any(p.aux, off + e, p.aux_dtype));
+            }
+        }
+        if (R) {
+            const long long roff = (long long)gm * p.ldr + gn;
+            if (full && fl.r_vec) {
+                const f32x4 r0 = *(const f32x4*)(R + roff), r1 = *(const f32x4*)(R + roff + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += R[roff + e];
+            }
+        }
+        if (full && fl.c_vec) {
+            if (p.out_dtype == AV_BF16) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                *(bf16x8*)((bf16_t*)p.C + off) = o;
+            } else {
+                *(f32x4*)((float*)p.C + off) = f32x4{v[0], v[1], v[2], v[3]};
+                *(f32x4*)((float*)p.C + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C, off + e, p.out_dtype, v[e]);
+        }
+    }
+}
+
+// ---- 2-D transpose with optional zero padding of the new inner dimension (out[C][Rpad]) -------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int C, long long ldi,
+                                                        int Rpad) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int rr = r0 + i, cc = c0 + tx;
+        tile[i][tx] = (rr < R && cc < C) ? to_f32<TI>(in[(long long)rr * ldi + cc]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int cc = c0 + i, rr = r0 + tx;
+        if (cc < C && rr < Rpad) out[(long long)cc * Rpad + rr] = from_f32<TO>(tile[tx][i]);
+    }
+}
+
+bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+}  // namespace
+
+// returns -1 when the arguments do not qualify for the fast path
+int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
+    if (p.in_dtype != AV_BF16 || p.a_mode != AV_A_ROWMAJOR || p.b_mode != AV_B_NK || p.stats) return -1;
+    if (p.K < BK || p.K % BK || p.lda % 8 || p.ldb % 8 || p.sA % 8 || p.sB % 8 || p.oA % 8 || p.oB % 8) return -1;
+    if (!al16(p.A) || !al16(p.B) || p.N <= 64 || p.M < 1) return -1;
+    const long long oes = p.out_dtype == AV_F32 ? 4 : 2;
+    FastFlags fl;
+    fl.c_vec = al16(p.C) && (!p.C2 || al16(p.C2)) && (p.ldc * oes) % 16 == 0 && (p.sC * oes) % 16 == 0 && (p.oC * oes) % 16 == 0;
+    fl.r_vec = p.R && al16(p.R) && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
+    const long long aes = p.aux_dtype == AV_F32 ? 4 : 2;
+    fl.aux_vec = p.aux && al16(p.aux) && (p.ldc * aes) % 16 == 0 && (p.sC * aes) % 16 == 0 && (p.oC * aes) % 16 == 0;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+            av_set_error("av_gemm(fast): cannot raise dynamic LDS to %d", LDS_BYTES);
+            return AV_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const int nbM = av_cdiv(p.M, BM), nbN = av_cdiv(p.N, BN);
+    dim3 grid((unsigned)(nbM * (long long)nbN), 1, (unsigned)p.batch);
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(NT), LDS_BYTES, st, p, nbM, nbN, fl);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_transpose(const void* in, int idt, void* out, int odt, int R, int C, long long ldi, int Rpad, void* stream) {
+    AV_CHECK(in && out && R > 0 && C > 0 && ldi >= C && Rpad >= R, "av_transpose: bad args R=%d C=%d ldi=%lld Rpad=%d", R, C, ldi, Rpad);
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((Rpad + 63) / 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (idt == AV_BF16 && odt == AV_BF16) hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, R, C, ldi, Rpad);
+    else if (idt == AV_F32 && odt == AV_BF16) hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)in, (bf16_t*)out, R, C, ldi, Rpad);
+    else if (idt == AV_F32 && odt == AV_F32) hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, st, (const float*)in, (float*)out, R, C, ldi, Rpad);
+    else if (idt == AV_BF16 && odt == AV_F32) hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)in, (float*)out, R, C, ldi, Rpad);
+    else { av_set_error("av_transpose: bad dtypes %d -> %d", idt, odt); return AV_ERR_ARG; }
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

@@ -112,6 +112,20 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, out_dtype: Op
     return out
 
 
+def transpose(x: Tensor, out_dtype: Optional[torch.dtype] = None, pad_to: int = 1) -> Tensor:
+    """[R, C] -> [C, Rpad] (Rpad = R rounded up to ``pad_to``, zero-filled)."""
+    R, Cc = x.shape
+    assert x.stride(1) == 1
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((Cc, Rp), dtype=out_dtype or x.dtype, device=x.device)
+    L.check(L.lib().av_transpose(ptr(x), dt(x), ptr(out), dt(out), R, Cc, x.stride(0), Rp, stream()), "av_transpose")
+    return out
+
+
+def _fast_ok(t: Tensor, K: int, N: int) -> bool:
+    return t.dtype == torch.bfloat16 and K >= 64 and N > 64
+
+
 def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, act: int = L.ACT_NONE,
               aux: Optional[Tensor] = None, R: Optional[Tensor] = None, out: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
     """y[M,N] = a[M,K] @ b[K,N]  (b row-major, e.g. dX = dY @ W with W [N_out,K_in])."""
@@ -121,6 +135,10 @@ def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, 
     assert b.shape[0] == K and a.is_contiguous() and b.is_contiguous()
     if out is None:
         out = torch.empty(a.shape[:-1] + (N,), dtype=out_dtype or a.dtype, device=a.device)
+    if _fast_ok(a, K, N) and K % 64 == 0:
+        bt = transpose(b)                        # [N, K]: K-contiguous operand for the fast LDS-DMA kernel
+        gemm(a, bt, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act, aux=aux, R=R, alpha=alpha)
+        return out
     gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_mode=L.B_KN, act=act, aux=aux, R=R, alpha=alpha)
     return out
 
@@ -132,6 +150,12 @@ def matmul_tn(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, alpha: floa
     assert b.shape[0] == Kk and a.is_contiguous() and b.is_contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if _fast_ok(a, Kk, N) and M > 64:
+        at = transpose(a, pad_to=64)             # [M, Kp]  token dimension becomes the contiguous K (zero padded)
+        bt = transpose(b, pad_to=64)             # [N, Kp]
+        Kp = at.shape[1]
+        gemm(at, bt, out, M=M, N=N, K=Kp, lda=Kp, ldb=Kp, ldc=N, alpha=alpha, R=out if accumulate else None)
+        return out
     gemm(a, b, out, M=M, N=N, K=Kk, lda=M, ldb=N, ldc=N, a_mode=L.A_TRANS, b_mode=L.B_KN, alpha=alpha,
          R=out if accumulate else None)
     return out

@@ -213,3 +213,43 @@ def test_attention_fwd_bwd(dtype, B, H, Tq, Tk, D, masked):
     torch.testing.assert_close(dq.float().permute(0, 2, 1, 3), qr.grad, **btol)
     torch.testing.assert_close(dk.float().permute(0, 2, 1, 3), kr.grad, **btol)
     torch.testing.assert_close(dv.float().permute(0, 2, 1, 3), vr.grad, **btol)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (6368, 1024, 1024), (300, 4096, 1024), (1000, 3072, 1024), (257, 800, 1024),
+                                   (6368, 1024, 4096), (199, 512, 1536), (130, 200, 192)])
+def test_fast_bf16_gemm(M, N, K):
+    """LDS-DMA fast path (bf16, K-contiguous operands) against fp64, with every epilogue."""
+    dtype = torch.bfloat16
+    x = _rand(M, K, dtype=dtype); w = _rand(N, K, dtype=dtype, scale=1 / math.sqrt(K)); b = _rand(N); r = _rand(M, N)
+    ref = _ref_mm(x, w.t())
+    torch.testing.assert_close(ops.linear(x, w, None, out_dtype=torch.float32), ref, rtol=2e-2, atol=2e-2)
+    pre = torch.empty(M, N, device="cuda", dtype=dtype)
+    y = ops.linear(x, w, b, out_dtype=dtype, act=L.ACT_GELU, C2=pre)
+    torch.testing.assert_close(pre.float(), ref + b, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(y.float(), torch.nn.functional.gelu(ref + b), rtol=2e-2, atol=2e-2)
+    out = r.clone()
+    ops.linear(x, w, b, out=out, R=out, alpha=0.5)
+    torch.testing.assert_close(out, 0.5 * ref + b + r, rtol=2e-2, atol=2e-2)
+    u = _rand(M, N, dtype=dtype)
+    g = ops.linear(x, w, None, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=u)
+    uu = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(uu).sum().backward()
+    torch.testing.assert_close(g.float(), ref * uu.grad, rtol=3e-2, atol=3e-2)
+
+
+def test_fast_layout_identity_asymmetric():
+    n = 256
+    a = torch.eye(n, device="cuda").to(torch.bfloat16)
+    w = (torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n) % 251 - 125).to(torch.bfloat16)
+    y = ops.linear(a, w, None, out_dtype=torch.float32)
+    torch.testing.assert_close(y, w.float().t().contiguous(), rtol=0, atol=0)
+
+
+def test_transpose_and_fast_nn_tn():
+    a = _rand(6368, 1024, dtype=torch.bfloat16); w = _rand(1024, 4096, dtype=torch.bfloat16, scale=1 / 32)
+    torch.testing.assert_close(ops.transpose(a).float(), a.float().t().contiguous(), rtol=0, atol=0)
+    tp = ops.transpose(a[:999], pad_to=64)
+    assert tp.shape == (1024, 1024) and float(tp[:, 999:].abs().max()) == 0.0
+    torch.testing.assert_close(ops.matmul_nn(a, w, out_dtype=torch.float32), _ref_mm(a, w), rtol=2e-2, atol=2e-2)
+    dy = _rand(6368, 4096, dtype=torch.bfloat16, scale=0.05)
+    torch.testing.assert_close(ops.matmul_tn(dy, a), _ref_mm(dy.t(), a), rtol=2e-2, atol=5e-2)
