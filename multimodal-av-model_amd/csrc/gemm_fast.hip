@@ -15,23 +15,64 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
-constexpr int TILE_B = BM * BK * 2;       // 16 KiB per operand per buffer
-constexpr int CLD = 132;                  // fp32 epilogue image leading dimension (floats)
-constexpr int LDS_BYTES = BM * CLD * 4;   // 67 584 B >= 4 * TILE_B
+constexpr int BM = 128, BK = 64, NT = 256;
+constexpr int TILE_A = BM * BK * 2;       // 16 KiB A tile per buffer
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile,
+__device__ __attribute__((aligned(256))) unsigned char g_zero_line[256];   // source of padded / out-of-range rows
+
+// NWI wave-instructions per wave, each filling 8 tile rows x 128 B (lane -> row sub = lane>>3, physical chunk lane&7;
+// the global chunk is pch ^ sub: XOR swizzle applied on the SOURCE side, LDS image stays lane-linear)
+template <int NWI>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile,
                                            int w, int lane) {
     const int sub = lane >> 3, pch = lane & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (w * 4 + i) * 8 + sub;
+    for (int i = 0; i < NWI; ++i) {
+        const int row = (w * NWI + i) * 8 + sub;
         int gr = row0 + row;
         if (gr > nrows - 1) gr = nrows - 1;                      // clamped rows are computed but never stored
         const bf16_t* src = base + (long long)gr * ld + k0 + ((pch ^ sub) << 3);
+        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * NWI + i) * 1024));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+    }
+}
+
+struct ConvRows { long long pix[4]; int iy0[4], ix0[4]; };
+
+__device__ __forceinline__ void conv_rows_init(ConvRows& cr, const av_gemm_args& p, int m0, int w, int lane) {
+    const int sub = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (w * 4 + i) * 8 + sub;
+        if (m < p.M) {
+            const int ox = m % p.cOw;
+            int q = m / p.cOw;
+            const int oy = q % p.cOh;
+            q /= p.cOh;
+            cr.pix[i] = (long long)q * p.cH * p.cW;
+            cr.iy0[i] = oy * p.cSh - p.cPh;
+            cr.ix0[i] = ox * p.cSw - p.cPw;
+        } else { cr.pix[i] = -1; cr.iy0[i] = 0; cr.ix0[i] = 0; }
+    }
+}
+
+// implicit im2col of an NHWC image: one K tile (64 channels) lies inside ONE filter tap (Cin % 64 == 0), so every
+// tile row is a contiguous 128-B run of the input pixel (or the zero line for padding / rows >= M)
+__device__ __forceinline__ void stage_conv(const bf16_t* __restrict__ base, const av_gemm_args& p, const ConvRows& cr, int k0, char* tile,
+                                           int w, int lane) {
+    const int sub = lane >> 3, pch = lane & 7;
+    const int tap = k0 / p.cCin, c0 = k0 - tap * p.cCin;
+    const int ky = tap / p.cKw, kx = tap - ky * p.cKw;
+    const int choff = (pch ^ sub) << 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int iy = cr.iy0[i] + ky, ix = cr.ix0[i] + kx;
+        const bool ok = cr.pix[i] >= 0 && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+        const bf16_t* src = ok ? base + ((cr.pix[i] + (long long)iy * p.cW + ix) * p.cCtot + p.cCoff + c0 + choff)
+                               : (const bf16_t*)g_zero_line + choff;
         const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 4 + i) * 1024));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
     }
@@ -39,10 +80,18 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, long
 
 struct FastFlags { int c_vec, r_vec, aux_vec; };
 
+// BNT = 128: waves 2(M) x 2(N), 64 x 64 each.   BNT = 64: waves 4(M) x 1(N), 32 x 64 each (N <= 64 problems:
+// ResNet layer1, grouped positional conv).   CONV: A operand is the implicit im2col of an NHWC image.
+template <int BNT, bool CONV>
 __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
+    constexpr int WM_T = BNT == 128 ? 4 : 2;                 // m-tiles per wave
+    constexpr int TILE_BB = BNT * BK * 2;                    // B tile bytes
+    constexpr int STAGE = TILE_A + TILE_BB;
+    constexpr int CLD = BNT + 4;                             // fp32 epilogue image leading dimension
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wrow = BNT == 128 ? (w >> 1) * 64 : w * 32;
+    const int wcol = BNT == 128 ? (w & 1) * 64 : 0;
     const int r = lane & 15, g = lane >> 4;
 
     // XCD-aware bijective remap: consecutive tile ids (sharing an A panel) land on the same XCD
@@ -53,47 +102,51 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
     }
     const int mb = bid / nbN, nb = bid - mb * nbN;
-    const int m0 = mb * BM, n0 = nb * BN;
+    const int m0 = mb * BM, n0 = nb * BNT;
     const int z = blockIdx.z;
     const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
     const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
     const bf16_t* A = (const bf16_t*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
     const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
 
-    f32x4 acc[4][4];
+    ConvRows cr;
+    if constexpr (CONV) conv_rows_init(cr, p, m0, w, lane);
+
+    f32x4 acc[WM_T][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM_T; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    auto stage = [&](int kt, char* buf) {
+        if constexpr (CONV) stage_conv(A, p, cr, kt * BK, buf, w, lane);
+        else stage_rows<4>(A, p.lda, m0, p.M, kt * BK, buf, w, lane);
+        stage_rows<BNT / 32>(B, p.ldb, n0, p.N, kt * BK, buf + TILE_A, w, lane);
+    };
+
     const int nk = p.K / BK;
-    stage_tile(A, p.lda, m0, p.M, 0, smem, w, lane);
-    stage_tile(B, p.ldb, n0, p.N, 0, smem + TILE_B, w, lane);
+    stage(0, smem);
     __syncthreads();
 
     // per-lane fragment addressing: row = base + 16*t + r (row & 7 == r & 7), chunk = 4*ks + g
     const int sw = r & 7;
-    const char* a_base = smem + (wm * 64 + r) * 128;
-    const char* b_base = smem + TILE_B + (wn * 64 + r) * 128;
+    const char* a_base = smem + (wrow + r) * 128;
+    const char* b_base = smem + TILE_A + (wcol + r) * 128;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            char* nxt = smem + (cur ^ 1) * 2 * TILE_B;
-            stage_tile(A, p.lda, m0, p.M, (kt + 1) * BK, nxt, w, lane);
-            stage_tile(B, p.ldb, n0, p.N, (kt + 1) * BK, nxt + TILE_B, w, lane);
-        }
-        const char* ab = a_base + cur * 2 * TILE_B;
-        const char* bb = b_base + cur * 2 * TILE_B;
+        if (kt + 1 < nk) stage(kt + 1, smem + (cur ^ 1) * STAGE);
+        const char* ab = a_base + cur * STAGE;
+        const char* bb = b_base + cur * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int choff = ((ks * 4 + g) ^ sw) << 4;
-            bf16x8 a[4], b[4];
+            bf16x8 a[WM_T], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(ab + i * 16 * 128 + choff);
+            for (int i = 0; i < WM_T; ++i) a[i] = *(const bf16x8*)(ab + i * 16 * 128 + choff);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(bb + j * 16 * 128 + choff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < WM_T; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -104,21 +157,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
     // ---------------- epilogue: accumulators -> fp32 LDS image -> row-contiguous vector stores ----------------
     float* cs = (float*)smem;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM_T; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                cs[(wm * 64 + i * 16 + 4 * g + e) * CLD + wn * 64 + j * 16 + r] = acc[i][j][e] * p.alpha;
+                cs[(wrow + i * 16 + 4 * g + e) * CLD + wcol + j * 16 + r] = acc[i][j][e] * p.alpha;
     __syncthreads();
 
     const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
     const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
     const float* bias = p.bias ? p.bias + (long long)zi * p.sBias : nullptr;
+    constexpr int CPR = BNT / 8;                             // 8-column chunks per tile row
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < BM * CPR / NT; ++it) {
         const int id = it * NT + tid;
-        const int row = id >> 4, cc = (id & 15) * 8;
+        const int row = id / CPR, cc = (id % CPR) * 8;
         const int gm = m0 + row, gn = n0 + cc;
         if (gm >= p.M || gn >= p.N) continue;
         float v[8];
@@ -186,6 +240,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
             for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C, off + e, p.out_dtype, v[e]);
         }
     }
+    if (p.stats) {   // train-mode BatchNorm partials: per-column sum / sum of squares over this block's valid rows
+        if (tid < BNT && n0 + tid < p.N) {
+            float s1 = 0.f, s2 = 0.f;
+            const int rows = p.M - m0 < BM ? p.M - m0 : BM;
+            for (int rr = 0; rr < rows; ++rr) {
+                const float v = cs[rr * CLD + tid];
+                s1 += v; s2 += v * v;
+            }
+            float* o = p.stats + (long long)mb * 2 * p.N;
+            o[n0 + tid] = s1;
+            o[p.N + n0 + tid] = s2;
+        }
+    }
 }
 
 // ---- 2-D transpose with optional zero padding of the new inner dimension (out[C][Rpad]) -------------------
@@ -210,30 +277,48 @@ bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 }  // namespace
 
+template <int BNT, bool CONV>
+int launch_fast(const av_gemm_args& p, hipStream_t st, const FastFlags& fl) {
+    constexpr int STAGE = TILE_A + BNT * BK * 2;
+    constexpr int EPI = BM * (BNT + 4) * 4;
+    constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    auto kern = gemm_nt_bf16_kernel<BNT, CONV>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            av_set_error("av_gemm(fast): cannot raise dynamic LDS to %d", LDS);
+            return AV_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const int nbM = av_cdiv(p.M, BM), nbN = av_cdiv(p.N, BNT);
+    dim3 grid((unsigned)(nbM * (long long)nbN), 1, (unsigned)p.batch);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, p, nbM, nbN, fl);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
 // returns -1 when the arguments do not qualify for the fast path
 int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
-    if (p.in_dtype != AV_BF16 || p.a_mode != AV_A_ROWMAJOR || p.b_mode != AV_B_NK || p.stats) return -1;
-    if (p.K < BK || p.K % BK || p.lda % 8 || p.ldb % 8 || p.sA % 8 || p.sB % 8 || p.oA % 8 || p.oB % 8) return -1;
-    if (!al16(p.A) || !al16(p.B) || p.N <= 64 || p.M < 1) return -1;
+    if (p.in_dtype != AV_BF16 || p.b_mode != AV_B_NK) return -1;
+    const bool conv = p.a_mode == AV_A_CONV2D;
+    if (!conv && p.a_mode != AV_A_ROWMAJOR) return -1;
+    if (p.K < BK || p.K % BK || p.ldb % 8 || p.sA % 8 || p.sB % 8 || p.oA % 8 || p.oB % 8) return -1;
+    if (!al16(p.A) || !al16(p.B) || p.M < 1 || p.N < 1) return -1;
+    if (conv) {
+        if (p.cCin % 64 || p.cCtot % 8 || p.cCoff % 8) return -1;
+    } else {
+        if (p.lda % 8 || p.stats) return -1;
+    }
     const long long oes = p.out_dtype == AV_F32 ? 4 : 2;
     FastFlags fl;
     fl.c_vec = al16(p.C) && (!p.C2 || al16(p.C2)) && (p.ldc * oes) % 16 == 0 && (p.sC * oes) % 16 == 0 && (p.oC * oes) % 16 == 0;
     fl.r_vec = p.R && al16(p.R) && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
     const long long aes = p.aux_dtype == AV_F32 ? 4 : 2;
     fl.aux_vec = p.aux && al16(p.aux) && (p.ldc * aes) % 16 == 0 && (p.sC * aes) % 16 == 0 && (p.oC * aes) % 16 == 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-            av_set_error("av_gemm(fast): cannot raise dynamic LDS to %d", LDS_BYTES);
-            return AV_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
-    const int nbM = av_cdiv(p.M, BM), nbN = av_cdiv(p.N, BN);
-    dim3 grid((unsigned)(nbM * (long long)nbN), 1, (unsigned)p.batch);
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(NT), LDS_BYTES, st, p, nbM, nbN, fl);
-    AV_LAUNCH_CHECK();
-    return AV_OK;
+    const bool narrow = p.N <= 64;
+    if (conv) return narrow ? launch_fast<64, true>(p, st, fl) : launch_fast<128, true>(p, st, fl);
+    return narrow ? launch_fast<64, false>(p, st, fl) : launch_fast<128, false>(p, st, fl);
 }
 
 extern "C" int av_transpose(const void* in, int idt, void* out, int odt, int R, int C, long long ldi, int Rpad, void* stream) {
