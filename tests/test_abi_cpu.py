@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library loads and exports every symbol include/av_hip.h declares; argument errors surface as
+status codes + av_last_error() (no kernel is launched without a GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT, pkg
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "av_hip.h"), encoding="utf-8").read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(av_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    L = pkg("_lib")
+    lib = L.lib()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/av_hip.h but not exported by libavhip.so"
+        assert n in L.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    assert sorted(L.SIGNATURES) == names, "ctypes table and header disagree"
+
+
+def test_errors_are_reported_not_aborted():
+    L = pkg("_lib")
+    lib = L.lib()
+    assert lib.av_version() >= 1
+    rc = lib.av_gemm(None, None)
+    assert rc != 0 and b"null" in lib.av_last_error()
+    a = L.GemmArgs()
+    a.A = a.B = a.C = 16
+    a.M, a.N, a.K, a.batch = 4, 4, 0, 1
+    assert lib.av_gemm(ctypes.byref(a), None) != 0 and b"bad shape" in lib.av_last_error()
+    assert lib.av_layernorm_fwd(None, 0, None, None, None, 0, None, None, 1, 8, 1e-5, 0, None) != 0
+    assert lib.av_attention_fwd(16, 16, 16, 16, None, 1, 1, 1, 4, 4, 48, 0, 0, 0, 0, 0, 0, 0, 0, None, 1.0, None) != 0
+    assert b"head_dim" in lib.av_last_error()
+    try:
+        L.check(1, "demo")
+        assert False
+    except RuntimeError as e:
+        assert "libavhip demo failed" in str(e)
+
+
+def test_gemm_args_struct_matches_header_layout():
+    """The ctypes mirror must have the same field order as `struct av_gemm_args`."""
+    L = pkg("_lib")
+    txt = open(os.path.join(ROOT, "include", "av_hip.h"), encoding="utf-8").read()
+    body = txt[txt.index("typedef struct av_gemm_args {"):txt.index("} av_gemm_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for stmt in body.split("{", 1)[1].split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        stmt = re.sub(r"^(const\s+)?(void|float|int|long long)\s*\*?", "", stmt).strip()
+        fields += [f.strip().lstrip("*").strip() for f in stmt.split(",")]
+    assert fields == [f[0] for f in L.GemmArgs._fields_], (fields, [f[0] for f in L.GemmArgs._fields_])

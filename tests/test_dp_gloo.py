@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient reducer and batch sharding used by the N>1 bench path."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module(PKG + ".parallel.dp"); synth = importlib.import_module(PKG + ".dataset.synthetic")
+    red = dp.GradBucketReducer()
+    assert red.world == world
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = [torch.randn(7, 5, generator=g), torch.randn(11, generator=g), None, torch.randn(3, 2, 2, generator=g)]
+    keep = [t.clone() for t in grads if t is not None]
+    b1 = red.reduce_async(grads[:2]); b2 = red.reduce_async(grads[2:])          # two buckets in flight
+    red.wait()
+    views = b1 + b2
+    # reference: explicit sum over ranks
+    gather = [None] * world
+    dist.all_gather_object(gather, [k.numpy() for k in keep])
+    for i, v in enumerate(views):
+        want = sum(torch.from_numpy(gather[r][i]) for r in range(world))
+        assert torch.allclose(v, want, atol=1e-6), (rank, i)
+        assert torch.allclose(v / world, want / world)
+    batch = synth.make_batch(4, 0.1, seed=3)
+    sh = dp.shard_batch(batch, rank, world)
+    assert sh["audio"].shape[0] == 2 and torch.equal(sh["audio"], batch["audio"][rank * 2:(rank + 1) * 2])
+    try:
+        dp.shard_batch(synth.make_batch(3, 0.1, seed=3), rank, world)
+        ok = False
+    except ValueError:
+        ok = True
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_bucket_allreduce_and_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, True), (1, True)]

@@ -1,0 +1,65 @@
+"""CPU: the oracle (oracle/av_oracle.py) re-checked against the fixtures captured from the reference itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _run(name, cfg_name):
+    from oracle import av_oracle as O
+    init = pkg("utils.init"); synth = pkg("dataset.synthetic")
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = getattr(init, cfg_name)
+    batch = synth.make_batch(int(fx["batch"]), float(fx["seconds"]), seed=int(fx["seed_batch"]), ragged=bool(fx["ragged"]))
+    sds = [init.visual_state_dict(), init.w2v2_state_dict(cfg), init.fusion_state_dict(512, cfg["hidden_size"], 512),
+           init.decoder_state_dict(1024, 800)]
+    proj = init.projection_params(cfg["hidden_size"])
+    return O, fx, cfg, batch, sds, proj
+
+
+def md(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+@pytest.mark.parametrize("name,cfg_name", [("tiny", "W2V2_TINY"), ("tiny_ragged", "W2V2_TINY")])
+def test_oracle_matches_reference_fixture(name, cfg_name):
+    O, fx, cfg, batch, sds, proj = _run(name, cfg_name)
+    with torch.no_grad():
+        ev = O.forward_losses(*[{k: v.clone() for k, v in sd.items()} for sd in sds], cfg, batch, proj, training=False)
+    assert md(ev["visual_feat1"], fx["eval_visual1"]) < 1e-4
+    assert md(ev["audio_last"].numpy()[..., ::8], fx["eval_audio_last"]) < 1e-4
+    assert md(ev["log_probs1"], fx["eval_log_probs1"]) < 1e-4 and md(ev["log_probs2"], fx["eval_log_probs2"]) < 1e-4
+    assert np.array_equal(ev["input_lengths1"].numpy(), fx["eval_input_lengths1"])
+    assert abs(float((ev["loss1"] + ev["loss2"]) / 2) - float(fx["eval_loss"])) < 1e-4
+    dec = []
+    for i in range(int(fx["batch"])):
+        dec += [O.greedy_ctc(ev["log_probs1"][i], 3), O.greedy_ctc(ev["log_probs2"][i], 3)]
+    assert dec == [[int(x) for x in s.split(",")] if s else [] for s in fx["eval_decoded"].tolist()]
+    out, grads = O.train_step(*sds, cfg, batch, proj, {})
+    assert md(out["log_probs1"], fx["train_log_probs1"]) < 1e-4
+    for k in ("loss1", "loss2", "contrast1", "contrast2", "total"):
+        assert abs(float(out[k]) - float(fx["train_" + k])) < 1e-4, k
+    none = sorted(k for k, g in grads.items() if g is None)          # oracle tracks the trainable keys only
+    fx_none = set(fx["none_grads"].tolist())                        # fixture lists every parameter without a gradient
+    assert none == sorted(k for k in fx_none if k in grads) and all(k.startswith("fusion.cross_attn_visual.") for k in none)
+    assert all(k in fx_none or g is not None for k, g in grads.items())
+    for key in fx.files:
+        if key.startswith("gradnorm/") and "k_proj.bias" not in key:
+            assert abs(float(grads[key[9:]].norm()) - float(fx[key])) / (float(fx[key]) + 1e-12) < 1e-4, key
+    for key in fx.files:
+        if key.startswith("bn_after/"):
+            assert md(sds[0][key[9:]], fx[key]) < 1e-5, key
+
+
+def test_oracle_c1_eval_fixture():
+    """Full-size wav2vec2-large eval forward of the oracle vs the reference capture (tests/golden/c1.npz)."""
+    O, fx, cfg, batch, sds, proj = _run("c1", "W2V2_LARGE")
+    with torch.no_grad():
+        last, mid = O.audio_forward(sds[1], cfg, batch["audio"], batch["mask1"] != 3)
+    assert md(last.numpy()[..., ::8], fx["eval_audio_last"]) < 1e-4
+    assert md(mid.numpy()[..., ::8], fx["eval_audio_mid"]) < 1e-4
