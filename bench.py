@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--lambda", dest="lambda_", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --same-device rehearses N>1 on a 1-GPU box")
+    ap.add_argument("--same-device", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,12 +91,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo")
 
     init = imp("utils.init"); synth = imp("dataset.synthetic"); enc = imp("model.encoder"); fm = imp("model.fusion_module")
     dm = imp("model.decoder"); tr = imp("model.trainer"); tok = imp("utils.tokenizer"); dp = imp("parallel.dp"); ops = imp("ops")
