@@ -53,6 +53,7 @@ def cpu_baseline(cfg, seconds):
     """The CPU oracle (checked against the reference in the build container) timed on this box's host cores."""
     from oracle import av_oracle as O
     init = imp("utils.init"); synth = imp("dataset.synthetic")
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))         # a 1-GPU box owns a 16-core CPU share
     B = 2
     batch = synth.make_batch(B, seconds, seed=42)
     sds = [init.visual_state_dict(), init.w2v2_state_dict(cfg), init.fusion_state_dict(512, cfg["hidden_size"], 512),
@@ -169,7 +170,7 @@ def main():
             tot_fl = sum(f for _, _, f in probe["records"])
             n = len(probe["records"])
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": f"gemm_kernel<{args.precision},128,rowmajor,NK> (nn.Linear / strided-conv forward GEMMs)",
+            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_kernel<128,false>" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>") + " (all nn.Linear-form products: forward, dX, dW, strided conv1d)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "launches_per_step": n // args.steps, "avg_launch_us": round(1000.0 * tot_ms / n, 2),
                     "algorithmic_gflop_per_launch": round(tot_fl / n / 1e9, 3)}

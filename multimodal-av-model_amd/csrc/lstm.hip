@@ -40,42 +40,69 @@ __device__ __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) 
     for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b[jj], acc, 0, 0, 0);
 }
 
+// K (= H) is split over the 4 wavefronts (the step is an L2-latency chain, not a throughput problem): every wave
+// accumulates a quarter of K for all row tiles, partials meet in LDS, wave w finishes row tile w.
+constexpr int MAXMT = 4;   // 64 rows per workgroup (blockIdx.z selects the 64-row group)
+
 template <typename T>
 __global__ __launch_bounds__(256) void lstm_fwd_step(const LstmFwdP p) {
     constexpr int KS = Frag<T>::KS, PER = Frag<T>::PER;
+    __shared__ float red[4][MAXMT][4][4][64];        // [wave][row tile][gate][acc reg][lane]  (64 KiB)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int d = blockIdx.y, j0 = blockIdx.x * 16, m0 = blockIdx.z * 64 + w * 16;
+    const int d = blockIdx.y, j0 = blockIdx.x * 16, mbase = blockIdx.z * 64;
     const int H = p.H, B = p.B;
     const int td = d == 0 ? p.s : p.T - 1 - p.s;           // time handled by this direction
     const int tp = d == 0 ? td - 1 : td + 1;               // previous time of the chain
-    f32x4 acc[4];
+    int nmt = (B - mbase + 15) / 16;
+    if (nmt > MAXMT) nmt = MAXMT;
+    if (p.s > 0) {
+        f32x4 acc[MAXMT][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.s > 0 && m0 < B) {
+        for (int mt = 0; mt < MAXMT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* hprev = (const T*)p.hseq + ((long long)tp * B) * 2 * H + d * H;          // row stride 2H
         const T* W = (const T*)p.whh + (long long)d * 4 * H * H;
-        const bool rowok = (m0 + r) < B;
-        const T* ap = hprev + (long long)(m0 + r) * 2 * H + PER * g;
-        for (int k0 = 0; k0 < H; k0 += KS) {
-            const auto a = ld_frag<T>(ap + k0, rowok);
+        const int kq = H / 4;
+        for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += KS) {
+            typename Frag<T>::type b[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const auto b = ld_frag<T>(W + (long long)(q * H + j0 + r) * H + k0 + PER * g, true);
-                mma(acc[q], a, b);
+            for (int q = 0; q < 4; ++q) b[q] = ld_frag<T>(W + (long long)(q * H + j0 + r) * H + k0 + PER * g, true);
+#pragma unroll
+            for (int mt = 0; mt < MAXMT; ++mt) {
+                if (mt < nmt) {
+                    const int row = mbase + mt * 16 + r;
+                    const auto a = ld_frag<T>(hprev + (long long)row * 2 * H + k0 + PER * g, row < B);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mma(acc[mt][q], a, b[q]);
+                }
             }
         }
+#pragma unroll
+        for (int mt = 0; mt < MAXMT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[w][mt][q][e][lane] = acc[mt][q][e];
     }
+    __syncthreads();
+    const int mt = w;                                       // wave w finishes row tile w
+    if (mt >= nmt) return;
     const int j = j0 + r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int row = m0 + 4 * g + e;
+        const int row = mbase + mt * 16 + 4 * g + e;
         if (row < B) {
+            float pre[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                pre[q] = p.s > 0 ? red[0][mt][q][e][lane] + red[1][mt][q][e][lane] + red[2][mt][q][e][lane] + red[3][mt][q][e][lane] : 0.f;
             const float* gxr = p.gx + (((long long)td * B + row) * 2 + d) * 4 * H;
-            const float ig = sigmoid_f(acc[0][e] + gxr[j]);
-            const float fg = sigmoid_f(acc[1][e] + gxr[H + j]);
-            const float gg = tanhf(acc[2][e] + gxr[2 * H + j]);
-            const float og = sigmoid_f(acc[3][e] + gxr[3 * H + j]);
+            const float ig = sigmoid_f(pre[0] + gxr[j]);
+            const float fg = sigmoid_f(pre[1] + gxr[H + j]);
+            const float gg = tanhf(pre[2] + gxr[2 * H + j]);
+            const float og = sigmoid_f(pre[3] + gxr[3 * H + j]);
             const float cprev = p.s > 0 ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;
             const float c = fg * cprev + ig * gg;
             const float h = og * tanhf(c);
@@ -105,32 +132,50 @@ struct LstmBwdP {
 template <typename T>
 __global__ __launch_bounds__(256) void lstm_bwd_step(const LstmBwdP p) {
     constexpr int KS = Frag<T>::KS, PER = Frag<T>::PER;
+    __shared__ float red[4][MAXMT][4][64];           // [wave][row tile][acc reg][lane]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int d = blockIdx.y, j0 = blockIdx.x * 16, m0 = blockIdx.z * 64 + w * 16;
+    const int d = blockIdx.y, j0 = blockIdx.x * 16, mbase = blockIdx.z * 64;
     const int H = p.H, B = p.B;
     const int td = d == 0 ? p.T - 1 - p.s : p.s;           // backward visits the chain in reverse
     const int tn = d == 0 ? td + 1 : td - 1;               // time handled at the previous backward step
     const int tp = d == 0 ? td - 1 : td + 1;               // forward-previous time (c_prev)
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.s > 0 && m0 < B) {                                // dh_rec = dgates[tn] x W_hh   (K = 4H)
+    int nmt = (B - mbase + 15) / 16;
+    if (nmt > MAXMT) nmt = MAXMT;
+    if (p.s > 0) {                                          // dh_rec = dgates[tn] x W_hh   (K = 4H, a quarter per wave)
+        f32x4 acc[MAXMT];
+#pragma unroll
+        for (int mt = 0; mt < MAXMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* A = (const T*)p.dgates + (((long long)tn * B) * 2 + d) * 4 * H;             // row stride 8H
         const T* Wt = (const T*)p.whhT + (long long)d * H * 4 * H;
-        const bool rowok = (m0 + r) < B;
-        const T* ap = A + (long long)(m0 + r) * 8 * H + PER * g;
         const T* bp = Wt + (long long)(j0 + r) * 4 * H + PER * g;
-        for (int k0 = 0; k0 < 4 * H; k0 += KS) {
-            const auto a = ld_frag<T>(ap + k0, rowok);
+        const int kq = H;                                   // 4H / 4
+        for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += KS) {
             const auto b = ld_frag<T>(bp + k0, true);
-            mma(acc, a, b);
+#pragma unroll
+            for (int mt = 0; mt < MAXMT; ++mt) {
+                if (mt < nmt) {
+                    const int row = mbase + mt * 16 + r;
+                    const auto a = ld_frag<T>(A + (long long)row * 8 * H + k0 + PER * g, row < B);
+                    mma(acc[mt], a, b);
+                }
+            }
         }
+#pragma unroll
+        for (int mt = 0; mt < MAXMT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[w][mt][e][lane] = acc[mt][e];
     }
+    __syncthreads();
+    const int mt = w;
+    if (mt >= nmt) return;
     const int j = j0 + r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int row = m0 + 4 * g + e;
+        const int row = mbase + mt * 16 + 4 * g + e;
         if (row < B) {
-            const float dh = ld_any(p.dout, (long long)row * p.do_bs + (long long)td * p.do_ts + d * H + j, p.dout_dtype) + acc[e];
+            const float rec = p.s > 0 ? red[0][mt][e][lane] + red[1][mt][e][lane] + red[2][mt][e][lane] + red[3][mt][e][lane] : 0.f;
+            const float dh = ld_any(p.dout, (long long)row * p.do_bs + (long long)td * p.do_ts + d * H + j, p.dout_dtype) + rec;
             const T* gs = (const T*)p.gates + (((long long)td * B + row) * 2 + d) * 4 * H;
             const float ig = to_f32<T>(gs[j]), fg = to_f32<T>(gs[H + j]), gg = to_f32<T>(gs[2 * H + j]), og = to_f32<T>(gs[3 * H + j]);
             const float c = p.cseq[(((long long)td * B + row) * 2 + d) * H + j];
@@ -154,7 +199,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step(const LstmBwdP p) {
 extern "C" int av_lstm_fwd_step(const float* gx, const void* whh, void* hseq, float* cseq, void* gates, void* out_bt, int dtype, int T,
                                 int B, int H, int s, void* stream) {
     AV_CHECK(gx && whh && hseq && cseq, "av_lstm_fwd_step: null pointer");
-    AV_CHECK(H > 0 && H % 32 == 0 && B > 0 && T > 0 && s >= 0 && s < T, "av_lstm_fwd_step: bad shape T=%d B=%d H=%d s=%d (H %% 32 == 0)", T, B, H, s);
+    AV_CHECK(H > 0 && H % 128 == 0 && B > 0 && T > 0 && s >= 0 && s < T, "av_lstm_fwd_step: bad shape T=%d B=%d H=%d s=%d (H %% 128 == 0)", T, B, H, s);
     AV_CHECK(dtype == AV_F32 || dtype == AV_BF16, "av_lstm_fwd_step: bad dtype %d", dtype);
     LstmFwdP p{gx, whh, hseq, cseq, gates, out_bt, T, B, H, s};
     dim3 grid((unsigned)(H / 16), 2, (unsigned)((B + 63) / 64));
@@ -167,7 +212,7 @@ extern "C" int av_lstm_fwd_step(const float* gx, const void* whh, void* hseq, fl
 extern "C" int av_lstm_bwd_step(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgates, const void* whhT,
                                 const void* gates, const float* cseq, float* dc, int dtype, int T, int B, int H, int s, void* stream) {
     AV_CHECK(dout && dgates && whhT && gates && cseq && dc, "av_lstm_bwd_step: null pointer");
-    AV_CHECK(H > 0 && H % 32 == 0 && B > 0 && T > 0 && s >= 0 && s < T, "av_lstm_bwd_step: bad shape T=%d B=%d H=%d s=%d", T, B, H, s);
+    AV_CHECK(H > 0 && H % 128 == 0 && B > 0 && T > 0 && s >= 0 && s < T, "av_lstm_bwd_step: bad shape T=%d B=%d H=%d s=%d", T, B, H, s);
     AV_CHECK(dtype == AV_F32 || dtype == AV_BF16, "av_lstm_bwd_step: bad dtype %d", dtype);
     LstmBwdP p{dout, dout_dtype, do_bs, do_ts, dgates, whhT, gates, cseq, dc, T, B, H, s};
     dim3 grid((unsigned)(H / 16), 2, (unsigned)((B + 63) / 64));
