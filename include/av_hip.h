@@ -134,6 +134,10 @@ int av_scatter_rows(const float* src, const long long* idx, float* out, long lon
                     void* stream);
 
 /* ---- lip-frame encoder glue (model/encoder.py:6-75): train-mode BatchNorm, PReLU, pooling; NHWC ------------ */
+/* bf16 fast path of the Conv3d(1->64,(5,7,7),(1,2,2),(2,3,3)) front-end (model/encoder.py:61): x [B*T][H][W] fp32,
+ * w bf16 [64][288] with k = (kt*7+ky)*8+kx (kx padded to 8, K padded to 288), y bf16 [B*T][H/2][W/2][64],
+ * stats [B*T*(H/16)*(W/32)][2][64] BatchNorm partials (optional). */
+int av_conv3d_front(const float* x, const void* w, void* y, float* stats, int B, int T, int H, int W, void* stream);
 int av_bn_finalize(const float* partial, int nblk, long long count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
                    float* shift, int C, double* ws /* 2C doubles */, void* stream);

@@ -1,0 +1,134 @@
+// Lip front-end Conv3d(1 -> 64, k (5,7,7), stride (1,2,2), pad (2,3,3), no bias) as an implicit GEMM on MFMA,
+// bf16 perf mode (model/encoder.py:61).  With one input channel an im2col matrix would be 245x the input, so the A
+// operand is never materialised: a workgroup keeps the 5 x 21 x 40 input patch of an 8 x 16 output tile in LDS and
+// every lane builds its MFMA A fragment straight from it.  The K axis is re-laid out as 35 (kt,ky) tap rows x 8
+// (kx padded 7 -> 8 with a zero weight) = 280 -> 288, so that one 16x16x32 fragment (8 consecutive k) is 8
+// CONTIGUOUS pixels of one patch row (4 x ds_read_b32, 4-byte aligned because the stride-2 window starts at an even
+// column).  The [64 x 288] weight image stays in LDS for the 6 tiles a workgroup processes.  Epilogue: fp32 LDS
+// image -> 16-B row-contiguous stores of the channel-last output + per-tile BatchNorm partial sums.
+#include "av_common.h"
+
+namespace {
+
+constexpr int KT = 5, KH = 7, KW = 7, TR = KT * KH;         // 35 tap rows
+constexpr int KPAD = 288, WLD = 296;                        // padded K, LDS weight row (bf16 elements)
+constexpr int TOY = 8, TOX = 16;                            // output tile
+constexpr int PH = 2 * TOY + 5, PW = 40;                    // patch rows / padded row width (needs 2*15+8 = 38)
+constexpr int CLD = 68;
+constexpr int W_BYTES = 64 * WLD * 2;                       // 37 888
+constexpr int R2_BYTES = 128 * CLD * 4;                     // 34 816 (>= patch 5*21*40*2 = 8 400)
+
+struct FrontP {
+    const float* x;      // [B*T][H][W] fp32 (single channel)
+    const bf16_t* w;     // [64][KPAD] : k = (kt*7+ky)*8 + kx
+    bf16_t* y;           // [B*T][Ho][Wo][64]
+    float* stats;        // [tiles][2][64] or null
+    int T, H, W, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Wl = (bf16_t*)smem;
+    bf16_t* patch = (bf16_t*)(smem + W_BYTES);
+    float* cs = (float*)(smem + W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int oxt = blockIdx.x, bt = blockIdx.y;
+    const int t = bt % p.T;
+    const int ox0 = oxt * TOX;
+
+    for (int i = tid; i < 64 * KPAD / 8; i += 256) {            // weights -> LDS, 16 B per thread
+        const int row = i / (KPAD / 8), ch = i % (KPAD / 8);
+        *(uint4*)(Wl + row * WLD + ch * 8) = *(const uint4*)(p.w + row * KPAD + ch * 8);
+    }
+    // tap rows handled by this lane: tr = 4*ks + g  (tr >= 35 multiplies zero weights: clamp the address)
+    int aoff[9];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
+        int tr = 4 * ks + g;
+        if (tr > TR - 1) tr = TR - 1;
+        const int kt = tr / KH, ky = tr - kt * KH;
+        aoff[ks] = (kt * PH + ky) * PW + 2 * r;                 // + 2*oy_l*PW added per row tile
+    }
+    const int ntile = p.Ho / TOY;
+    for (int oyt = 0; oyt < ntile; ++oyt) {
+        const int oy0 = oyt * TOY;
+        __syncthreads();                                        // previous tile's image reads are done
+        for (int i = tid; i < KT * PH * PW; i += 256) {
+            const int px = i % PW, q = i / PW;
+            const int py = q % PH, kt = q / PH;
+            const int ti = t + kt - 2, iy = 2 * oy0 - 3 + py, ix = 2 * ox0 - 3 + px;
+            float v = 0.f;
+            if (ti >= 0 && ti < p.T && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = p.x[((long long)(bt + kt - 2) * p.H + iy) * p.W + ix];
+            patch[i] = (bf16_t)v;
+        }
+        __syncthreads();
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) {
+            bf16x8 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(Wl + (j * 16 + r) * WLD + ks * 32 + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned* ap = (const unsigned*)(patch + aoff[ks] + 2 * (2 * w + i) * PW);
+                uint4 av = make_uint4(ap[0], ap[1], ap[2], ap[3]);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                        // all patch reads done: the image may overwrite it
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cs[((2 * w + i) * 16 + 4 * g + e) * CLD + j * 16 + r] = acc[i][j][e];   // pixel = oy_l*16 + ox_l
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int id = it * 256 + tid;
+            const int pix = id >> 3, cc = (id & 7) * 8;
+            const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+            const f32x4 v0 = *(const f32x4*)(cs + pix * CLD + cc), v1 = *(const f32x4*)(cs + pix * CLD + cc + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v0[e]; o[4 + e] = (bf16_t)v1[e]; }
+            *(bf16x8*)(p.y + (((long long)bt * p.Ho + oy) * p.Wo + ox) * 64 + cc) = o;
+        }
+        if (p.stats && tid < 64) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int rr = 0; rr < 128; ++rr) { const float v = cs[rr * CLD + tid]; s1 += v; s2 += v * v; }
+            float* o = p.stats + (((long long)bt * ntile + oyt) * gridDim.x + oxt) * 128;
+            o[tid] = s1; o[64 + tid] = s2;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int av_conv3d_front(const float* x, const void* w, void* y, float* stats, int B, int T, int H, int W, void* stream) {
+    AV_CHECK(x && w && y && B > 0 && T > 0, "av_conv3d_front: bad args");
+    AV_CHECK(H % 16 == 0 && W % 32 == 0, "av_conv3d_front: H=%d must be a multiple of 16 and W=%d of 32", H, W);
+    FrontP p{x, (const bf16_t*)w, (bf16_t*)y, stats, T, H, W, H / 2, W / 2};
+    static bool done = false;
+    const int lds = W_BYTES + R2_BYTES;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)conv3d_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            av_set_error("av_conv3d_front: cannot raise dynamic LDS to %d", lds);
+            return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    dim3 grid((unsigned)(p.Wo / TOX), (unsigned)(B * T));
+    hipLaunchKernelGGL(conv3d_front_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

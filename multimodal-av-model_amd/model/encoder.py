@@ -123,6 +123,20 @@ class VisualEncoder(nn.Module):
             self._wcache[key] = hit
         return hit[1]
 
+    def _w_front(self, conv: nn.Module):
+        """[64,1,5,7,7] -> bf16 [64][288]: k = (kt*7+ky)*8 + kx, kx padded 7->8 and K padded 280->288 with zeros."""
+        p = conv.weight
+        key = ("front", id(p))
+        ver = (p._version, p.data_ptr())
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                w = torch.zeros((64, 36, 8), dtype=torch.float32, device=p.device)
+                w[:, :35, :7] = p.data.reshape(64, 35, 7)
+                hit = (ver, ops.cast(w.reshape(64, 288).contiguous(), torch.bfloat16))
+            self._wcache[key] = hit
+        return hit[1]
+
     def _bn(self, bn: nn.Module, stats, nblk: int, count: int, training: bool):
         C = bn.num_features
         dev = bn.weight.device
@@ -163,18 +177,26 @@ class VisualEncoder(nn.Module):
         B, C, T, H, W = x.shape
         assert C == 1
         dev = x.device
-        xin = ops.cast(x.contiguous().float().view(B, T, H, W), dtype)
         conv0 = self.frontend3D[0]
         kt, kh, kw = conv0.kernel_size
         Ho, Wo = (H + 2 * conv0.padding[1] - kh) // conv0.stride[1] + 1, (W + 2 * conv0.padding[2] - kw) // conv0.stride[2] + 1
         M = B * T * Ho * Wo
         y = torch.empty((M, 64), dtype=dtype, device=dev)
-        nblk = (M + 127) // 128
-        stats = torch.empty((nblk, 2, 64), dtype=torch.float32, device=dev) if training else None
-        geo = dict(cT=T, cH=H, cW=W, cCtot=1, cCin=1, cCoff=0, cKt=kt, cKh=kh, cKw=kw, cSh=conv0.stride[1], cSw=conv0.stride[2],
-                   cPt=conv0.padding[0], cPh=conv0.padding[1], cPw=conv0.padding[2], cOh=Ho, cOw=Wo)
-        ops.gemm(xin, self._w(conv0, dtype), y, M=M, N=64, K=kt * kh * kw, lda=0, ldb=kt * kh * kw, ldc=64, a_mode=L.A_CONV3D1,
-                 conv=geo, stats=stats)
+        fast = (dtype == torch.bfloat16 and (kt, kh, kw) == (5, 7, 7) and tuple(conv0.stride) == (1, 2, 2)
+                and tuple(conv0.padding) == (2, 3, 3) and H % 16 == 0 and W % 32 == 0)
+        if fast:    # patch-in-LDS implicit GEMM (frontend3d.hip); one BN partial per 8x16 output tile
+            nblk = B * T * (Ho // 8) * (Wo // 16)
+            stats = torch.empty((nblk, 2, 64), dtype=torch.float32, device=dev) if training else None
+            L.check(L.lib().av_conv3d_front(ops.ptr(x.contiguous().float()), ops.ptr(self._w_front(conv0)), ops.ptr(y), ops.ptr(stats),
+                                            B, T, H, W, ops.stream()), "av_conv3d_front")
+        else:
+            xin = ops.cast(x.contiguous().float().view(B, T, H, W), dtype)
+            nblk = (M + 127) // 128
+            stats = torch.empty((nblk, 2, 64), dtype=torch.float32, device=dev) if training else None
+            geo = dict(cT=T, cH=H, cW=W, cCtot=1, cCin=1, cCoff=0, cKt=kt, cKh=kh, cKw=kw, cSh=conv0.stride[1], cSw=conv0.stride[2],
+                       cPt=conv0.padding[0], cPh=conv0.padding[1], cPw=conv0.padding[2], cOh=Ho, cOw=Wo)
+            ops.gemm(xin, self._w(conv0, dtype), y, M=M, N=64, K=kt * kh * kw, lda=0, ldb=kt * kh * kw, ldc=64, a_mode=L.A_CONV3D1,
+                     conv=geo, stats=stats)
         sc, sh = self._bn(self.frontend3D[1], stats, nblk, M, training)
         N = B * T
         Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1

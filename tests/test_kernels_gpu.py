@@ -253,3 +253,22 @@ def test_transpose_and_fast_nn_tn():
     torch.testing.assert_close(ops.matmul_nn(a, w, out_dtype=torch.float32), _ref_mm(a, w), rtol=2e-2, atol=2e-2)
     dy = _rand(6368, 4096, dtype=torch.bfloat16, scale=0.05)
     torch.testing.assert_close(ops.matmul_tn(dy, a), _ref_mm(dy.t(), a), rtol=2e-2, atol=5e-2)
+
+
+def test_conv3d_front_fast_kernel():
+    B, T, H = 2, 7, 96
+    x = torch.rand(B, T, H, H, device="cuda")
+    w = torch.randn(64, 1, 5, 7, 7, device="cuda") / math.sqrt(245)
+    wk = torch.zeros(64, 36, 8, device="cuda"); wk[:, :35, :7] = w.reshape(64, 35, 7)
+    wk = wk.reshape(64, 288).to(torch.bfloat16).contiguous()
+    Ho = H // 2
+    y = torch.empty(B * T * Ho * Ho, 64, device="cuda", dtype=torch.bfloat16)
+    nblk = B * T * (Ho // 8) * (Ho // 16)
+    stats = torch.zeros(nblk, 2, 64, device="cuda")
+    L.check(L.lib().av_conv3d_front(ops.ptr(x), ops.ptr(wk), ops.ptr(y), ops.ptr(stats), B, T, H, H, ops.stream()))
+    xr = x.to(torch.bfloat16).double()[:, None]
+    ref = torch.nn.functional.conv3d(xr, w.to(torch.bfloat16).double(), None, (1, 2, 2), (2, 3, 3)).float()
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(-1, 64)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(stats[:, 0].sum(0), ref.sum(0), rtol=2e-3, atol=0.5)
+    torch.testing.assert_close(stats[:, 1].sum(0), (ref * ref).sum(0), rtol=2e-3, atol=0.5)
