@@ -68,6 +68,26 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// bf16 perf path: Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7, far below bf16 resolution) with one exp + one rcp;
+// erf and the Gaussian density share the exponential
+__device__ __forceinline__ void erf_pdf_fast(float x, float& erfv, float& ex) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    ex = __expf(-z * z);                                   // = exp(-x^2/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * ex;
+    erfv = x < 0.f ? -e : e;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float e, ex;
+    erf_pdf_fast(x, e, ex);
+    return 0.5f * x * (1.0f + e);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float e, ex;
+    erf_pdf_fast(x, e, ex);
+    return 0.5f * (1.0f + e) + x * 0.39894228040143267794f * ex;
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 static inline int av_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

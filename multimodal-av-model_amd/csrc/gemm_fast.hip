@@ -169,6 +169,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
     const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
     const float* bias = p.bias ? p.bias + (long long)zi * p.sBias : nullptr;
     constexpr int CPR = BNT / 8;                             // 8-column chunks per tile row
+    float bv[8];                                             // the thread's 8 columns are the same in every iteration
+    {
+        const int gnt = n0 + (tid % CPR) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (bias && gnt + e < p.N) ? bias[gnt + e] : 0.f;
+    }
 #pragma unroll
     for (int it = 0; it < BM * CPR / NT; ++it) {
         const int id = it * NT + tid;
@@ -181,10 +187,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
         for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
         const bool full = gn + 8 <= p.N;
         const long long off = cbase + (long long)gm * p.ldc + gn;
-        if (bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (full || gn + e < p.N) v[e] += bias[gn + e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
         if (p.C2) {
             if (full && fl.c_vec) {
                 if (p.out_dtype == AV_BF16) {
@@ -203,15 +207,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
         }
         if (p.act == AV_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
         } else if (p.act == AV_ACT_MUL_GELU_GRAD) {
             if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
                 const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)u[e]);
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u[e]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_f(ld_any(p.aux, off + e, p.aux_dtype));
+                for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_fast(ld_any(p.aux, off + e, p.aux_dtype));
             }
         }
         if (R) {
