@@ -7,7 +7,7 @@ namespace {
 
 constexpr int MAXIT = 32;  // 64 lanes x 32 = rows up to 2048 columns
 
-template <int ACT>
+template <int ACT, int NIT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, int xdt, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ y, int ydt,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o,
@@ -16,10 +16,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const long long base = row * cols;
-    float v[MAXIT];
+    float v[NIT];
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = lane + 64 * it;
         v[it] = c < cols ? ld_any(x, base + c, xdt) : 0.f;
         s += v[it];
@@ -27,14 +27,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     const float mean = wave_sum(s) / cols;
     float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = lane + 64 * it;
         const float d = c < cols ? v[it] - mean : 0.f;
         q += d * d;
     }
     const float rstd = rsqrtf(wave_sum(q) / cols + eps);
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = lane + 64 * it;
         if (c < cols) {
             float o = (v[it] - mean) * rstd * gamma[c] + beta[c];
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block
+template <int NIT, bool PG>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, int xdt, const void* __restrict__ dy, int dydt,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
@@ -59,23 +60,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
     long long r_end = r_begin + rows_per_block;
     if (r_end > rows) r_end = rows;
-    float dg[MAXIT], db[MAXIT];
+    float dg[PG ? NIT : 1], db[PG ? NIT : 1];
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) { dg[it] = 0.f; db[it] = 0.f; }
+    for (int it = 0; it < (PG ? NIT : 1); ++it) { dg[it] = 0.f; db[it] = 0.f; }
     for (long long row = r_begin + w; row < r_end; row += 4) {
         const long long base = row * cols;
         const float mu = mean[row], rs = rstd[row];
-        float xh[MAXIT], g[MAXIT];
+        float xh[NIT], g[NIT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int c = lane + 64 * it;
             if (c < cols) {
                 const float d = ld_any(dy, base + c, dydt);
                 xh[it] = (ld_any(x, base + c, xdt) - mu) * rs;
                 g[it] = d * gamma[c];
-                dg[it] += d * xh[it];
-                db[it] += d;
+                if (PG) { dg[it] += d * xh[it]; db[it] += d; }
                 s1 += g[it];
                 s2 += g[it] * xh[it];
             } else { xh[it] = 0.f; g[it] = 0.f; }
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
         s1 = wave_sum(s1) / cols;
         s2 = wave_sum(s2) / cols;
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int c = lane + 64 * it;
             if (c < cols) {
                 float o = rs * (g[it] - s1 - xh[it] * s2);
@@ -92,12 +92,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
             }
         }
     }
-    if (dgb) {   // combine the 4 waves, write [blk][2][cols]
+    if (PG && dgb) {   // combine the 4 waves, write [blk][2][cols]
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             if (64 * it >= cols) break;
-            red[w][0][lane] = dg[it];
-            red[w][1][lane] = db[it];
+            red[w][0][lane] = dg[PG ? it : 0];
+            red[w][1][lane] = db[PG ? it : 0];
             __syncthreads();
             if (w == 0) {
                 const int c = lane + 64 * it;
@@ -219,10 +219,12 @@ extern "C" int av_layernorm_fwd(const void* x, int xdt, const float* gamma, cons
     AV_CHECK(act == AV_ACT_NONE || act == AV_ACT_GELU, "av_layernorm_fwd: bad act %d", act);
     if (rows == 0) return AV_OK;
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (act == AV_ACT_GELU)
-        hipLaunchKernelGGL(ln_fwd_kernel<AV_ACT_GELU>, grid, dim3(256), 0, (hipStream_t)stream, x, xdt, gamma, beta, y, ydt, mean, rstd, rows, cols, eps);
-    else
-        hipLaunchKernelGGL(ln_fwd_kernel<AV_ACT_NONE>, grid, dim3(256), 0, (hipStream_t)stream, x, xdt, gamma, beta, y, ydt, mean, rstd, rows, cols, eps);
+#define LN_FWD(A, N) hipLaunchKernelGGL((ln_fwd_kernel<A, N>), grid, dim3(256), 0, (hipStream_t)stream, x, xdt, gamma, beta, y, ydt, mean, rstd, rows, cols, eps)
+#define LN_FWD_N(A) do { if (cols <= 64) LN_FWD(A, 1); else if (cols <= 128) LN_FWD(A, 2); else if (cols <= 512) LN_FWD(A, 8); \
+                         else if (cols <= 1024) LN_FWD(A, 16); else LN_FWD(A, 32); } while (0)
+    if (act == AV_ACT_GELU) LN_FWD_N(AV_ACT_GELU); else LN_FWD_N(AV_ACT_NONE);
+#undef LN_FWD_N
+#undef LN_FWD
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -234,9 +236,14 @@ extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt
     AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_layernorm_bwd: cols=%d out of range", cols);
     AV_CHECK(nblk >= 1, "av_layernorm_bwd: nblk=%d", nblk);
     if (rows == 0) return AV_OK;
+    if (!dgb_partial) nblk = (int)((rows + 3) / 4 > 65535 * 16 ? 65535 * 16 : (rows + 3) / 4);   // no partials: one row per wave
     const long long rpb = (rows + nblk - 1) / nblk;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx,
-                       dgb_partial, rows, cols, rpb);
+#define LN_BWD(N, P) hipLaunchKernelGGL((ln_bwd_kernel<N, P>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx, dgb_partial, rows, cols, rpb)
+#define LN_BWD_N(P) do { if (cols <= 64) LN_BWD(1, P); else if (cols <= 128) LN_BWD(2, P); else if (cols <= 512) LN_BWD(8, P); \
+                         else if (cols <= 1024) LN_BWD(16, P); else LN_BWD(32, P); } while (0)
+    if (dgb_partial) LN_BWD_N(true); else LN_BWD_N(false);
+#undef LN_BWD_N
+#undef LN_BWD
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -109,6 +109,86 @@ __global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out,
     }
 }
 
+// ---- bf16 vector forms: one thread = 8 consecutive channels of one pixel (16-B accesses, C % 8 == 0) -------------
+__global__ __launch_bounds__(256) void bn_act_vec_kernel(const bf16x8* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const bf16x8* __restrict__ res,
+                                                         const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                         const float* __restrict__ slope, bf16x8* __restrict__ out, long long n8, int C8) {
+    const long long stride = (long long)gridDim.x * blockDim.x;      // multiple of C8 (host guarantees) => fixed channel group
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = (int)(e % C8) * 8;
+    float sc[8], sh[8], rs[8], rb[8], sl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = scale[cg + i]; sh[i] = shift[cg + i];
+        rs[i] = rscale ? rscale[cg + i] : 1.f; rb[i] = rscale ? rshift[cg + i] : 0.f;
+        sl[i] = slope ? slope[cg + i] : 1.f;
+    }
+    for (; e < n8; e += stride) {
+        const bf16x8 xv = x[e];
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)xv[i] * sc[i] + sh[i];
+        if (res) {
+            const bf16x8 rv = res[e];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)rv[i] * rs[i] + rb[i];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)(v[i] >= 0.f ? v[i] : v[i] * sl[i]);
+        out[e] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_prelu_maxpool_vec_kernel(const bf16x8* __restrict__ x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ slope,
+                                                                   bf16x8* __restrict__ out, long long N, int H, int W, int C8) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long tot = N * Ho * Wo * C8;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cgi = (int)(e % C8), cg = cgi * 8;
+    float sc[8], sh[8], sl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = scale[cg + i]; sh[i] = shift[cg + i]; sl[i] = slope[cg + i]; }
+    for (; e < tot; e += stride) {
+        long long q = e / C8;
+        const int ox = (int)(q % Wo); q /= Wo;
+        const int oy = (int)(q % Ho);
+        const long long img = q / Ho;
+        float m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if (ix < 0 || ix >= W) continue;
+                const bf16x8 xv = x[((img * H + iy) * W + ix) * C8 + cgi];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = (float)xv[i] * sc[i] + sh[i];
+                    v = v >= 0.f ? v : v * sl[i];
+                    m[i] = fmaxf(m[i], v);
+                }
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)m[i];
+        out[e] = o;
+    }
+}
+
+inline int vec_grid(long long n8, int C8) {          // blocks of 256 threads; total threads a multiple of C8 (C8 | 256 here)
+    long long b = (n8 + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
 inline int ew_grid(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -137,7 +217,12 @@ extern "C" int av_bn_act(const void* x, const float* scale, const float* shift, 
                          const float* slope, void* out, int dtype, long long n, int C, void* stream) {
     AV_CHECK(x && scale && shift && out && C > 0, "av_bn_act: null pointer");
     if (n == 0) return AV_OK;
-    if (dtype == AV_F32)
+    const bool vec = dtype == AV_BF16 && C % 8 == 0 && 256 % (C / 8) == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                     (!res || (uintptr_t)res % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(bn_act_vec_kernel, dim3(vec_grid(n / 8, C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, scale, shift,
+                           (const bf16x8*)res, rscale, rshift, slope, (bf16x8*)out, n / 8, C / 8);
+    else if (dtype == AV_F32)
         hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, shift, (const float*)res, rscale, rshift, slope, (float*)out, n, C);
     else
         hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift, (const bf16_t*)res, rscale, rshift, slope, (bf16_t*)out, n, C);
@@ -151,7 +236,11 @@ extern "C" int av_bn_prelu_maxpool(const void* x, const float* scale, const floa
     if (N == 0) return AV_OK;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long tot = N * Ho * Wo * C;
-    if (dtype == AV_F32)
+    const bool vec = dtype == AV_BF16 && C % 8 == 0 && 256 % (C / 8) == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(bn_prelu_maxpool_vec_kernel, dim3(vec_grid(tot / 8, C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, scale,
+                           shift, slope, (bf16x8*)out, N, H, W, C / 8);
+    else if (dtype == AV_F32)
         hipLaunchKernelGGL(bn_prelu_maxpool_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, shift, slope, (float*)out, N, H, W, C);
     else
         hipLaunchKernelGGL(bn_prelu_maxpool_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift, slope, (bf16_t*)out, N, H, W, C);

@@ -280,12 +280,12 @@ class Wav2Vec2ModelHIP(nn.Module):
             dh3 = dh
             dh3_t = ops.cast(dh3, dtype)
             W2 = self.c(p + "feed_forward.output_dense.weight", dtype)            # [Hd, I]
-            du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I))
+            du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I), b_is_weight=True)
             if tr:
                 grads[p + "feed_forward.output_dense.weight"] = ops.matmul_tn(dh3_t.view(M, Hd), s["g"].view(M, I))
                 grads[p + "feed_forward.output_dense.bias"] = ops.colsum(dh3.view(M, Hd))
             W1 = self.c(p + "feed_forward.intermediate_dense.weight", dtype)      # [I, Hd]
-            dx2 = ops.matmul_nn(du, W1, out_dtype=dtype)
+            dx2 = ops.matmul_nn(du, W1, out_dtype=dtype, b_is_weight=True)
             if tr:
                 grads[p + "feed_forward.intermediate_dense.weight"] = ops.matmul_tn(du, s["x2"].view(M, Hd))
                 grads[p + "feed_forward.intermediate_dense.bias"] = ops.colsum(du)
@@ -297,14 +297,14 @@ class Wav2Vec2ModelHIP(nn.Module):
                 dh2 = r
             dh2_t = ops.cast(dh2, dtype)
             Wo = self.c(p + "attention.out_proj.weight", dtype)
-            dao = ops.matmul_nn(dh2_t.view(M, Hd), Wo, out_dtype=dtype).view(B, T, nh, hd)
+            dao = ops.matmul_nn(dh2_t.view(M, Hd), Wo, out_dtype=dtype, b_is_weight=True).view(B, T, nh, hd)
             if tr:
                 grads[p + "attention.out_proj.weight"] = ops.matmul_tn(dh2_t.view(M, Hd), s["ao"].view(M, Hd))
                 grads[p + "attention.out_proj.bias"] = ops.colsum(dh2.view(M, Hd))
             qkv = s["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dao, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx["klen"], scale)
-            dx1 = ops.matmul_nn(dqkv.view(M, 3 * Hd), self.qkv_w(li, dtype), out_dtype=dtype)
+            dx1 = ops.matmul_nn(dqkv.view(M, 3 * Hd), self.qkv_w(li, dtype), out_dtype=dtype, b_is_weight=True)
             if tr:
                 dW = ops.matmul_tn(dqkv.view(M, 3 * Hd), s["x1"].view(M, Hd))
                 db = ops.colsum(dqkv.view(M, 3 * Hd))

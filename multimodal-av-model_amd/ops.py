@@ -122,12 +122,30 @@ def transpose(x: Tensor, out_dtype: Optional[torch.dtype] = None, pad_to: int = 
     return out
 
 
+_WT_CACHE = {}
+
+
+def transpose_cached(b: Tensor) -> Tensor:
+    """W^T of a weight-like operand, cached on (storage, version): frozen layers transpose once, trained ones per step."""
+    key = (b.data_ptr(), tuple(b.shape), b.dtype)
+    ver = b._version
+    hit = _WT_CACHE.get(key)
+    if hit is None or hit[0] != ver or hit[2]() is not b:
+        import weakref
+        hit = (ver, transpose(b), weakref.ref(b))
+        if len(_WT_CACHE) > 512:
+            _WT_CACHE.clear()
+        _WT_CACHE[key] = hit
+    return hit[1]
+
+
 def _fast_ok(t: Tensor, K: int, N: int) -> bool:
     return t.dtype == torch.bfloat16 and K >= 64 and N > 64
 
 
 def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, act: int = L.ACT_NONE,
-              aux: Optional[Tensor] = None, R: Optional[Tensor] = None, out: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+              aux: Optional[Tensor] = None, R: Optional[Tensor] = None, out: Optional[Tensor] = None, alpha: float = 1.0,
+              b_is_weight: bool = False) -> Tensor:
     """y[M,N] = a[M,K] @ b[K,N]  (b row-major, e.g. dX = dY @ W with W [N_out,K_in])."""
     K = a.shape[-1]
     M = a.numel() // K
@@ -136,7 +154,7 @@ def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, 
     if out is None:
         out = torch.empty(a.shape[:-1] + (N,), dtype=out_dtype or a.dtype, device=a.device)
     if _fast_ok(a, K, N) and K % 64 == 0:
-        bt = transpose(b)                        # [N, K]: K-contiguous operand for the fast LDS-DMA kernel
+        bt = transpose_cached(b) if b_is_weight else transpose(b)   # [N, K]: K-contiguous operand for the fast kernel
         gemm(a, bt, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act, aux=aux, R=R, alpha=alpha)
         return out
     gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_mode=L.B_KN, act=act, aux=aux, R=R, alpha=alpha)
