@@ -124,10 +124,12 @@ int av_lstm_bwd_step(const void* dout, int dout_dtype, long long do_bs, long lon
 
 /* ---- fusion glue without host syncs (model/fusion_module.py:40-55,66; model/trainer.py:98,102) ------------- */
 int av_mask_downsample(const long long* mask, long long* out, int B, int Tin, int Tout, void* stream);
-/* ws_i32: B*Ta + B + 1 ints (compaction index, counts, batch max) kept for the backward */
+/* ws_i32: B*Ta + B + groups ints (compaction index, counts, per-group batch max) kept for the backward;
+ * the reference's "pad to the batch maximum" is evaluated per group of B/groups consecutive items */
 int av_fusion_gather_lerp_fwd(const float* feat, const long long* mask, int* ws_i32, float* out, long long* mask_out,
-                              long long* lens, int B, int Ta, int Tv, int D, void* stream);
-int av_fusion_gather_lerp_bwd(const float* dout, const int* ws_i32, float* dfeat, int B, int Ta, int Tv, int D, void* stream);
+                              long long* lens, int B, int Ta, int Tv, int D, int groups, void* stream);
+int av_fusion_gather_lerp_bwd(const float* dout, const int* ws_i32, float* dfeat, int B, int Ta, int Tv, int D, int groups,
+                              void* stream);
 int av_permute_bt(const void* in, int idt, void* out, int odt, int B, int T, int D, void* stream); /* [B,T,D]->[T,B,D] */
 int av_gather_rows(const void* src, int sdt, const long long* idx, void* out, int odt, long long n, int D, void* stream);
 int av_scatter_rows(const float* src, const long long* idx, float* out, long long n, int D, float alpha, int accumulate,

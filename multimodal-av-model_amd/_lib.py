@@ -54,8 +54,8 @@ SIGNATURES = {
     "av_lstm_fwd_step": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "av_lstm_bwd_step": [vp, i32, ll, ll, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "av_mask_downsample": [vp, vp, i32, i32, i32, vp],
-    "av_fusion_gather_lerp_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "av_fusion_gather_lerp_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "av_fusion_gather_lerp_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "av_fusion_gather_lerp_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "av_permute_bt": [vp, i32, vp, i32, i32, i32, i32, vp],
     "av_gather_rows": [vp, i32, vp, vp, i32, ll, i32, vp],
     "av_scatter_rows": [vp, vp, vp, ll, i32, f32, i32, vp],

@@ -21,7 +21,7 @@ __global__ void mask_down_kernel(const long long* __restrict__ m, long long* __r
 
 // idx[b][0..cnt) = positions with mask in {1,2}, in order; cnt[b]; tmax = max_b cnt[b]
 __global__ __launch_bounds__(256) void compact_kernel(const long long* __restrict__ mask, int* __restrict__ idx, int* __restrict__ cnt,
-                                                      int* __restrict__ tmax, int Ta) {
+                                                      int* __restrict__ tmax, int Ta, int gsize) {
     __shared__ int wsum[4];
     __shared__ int base_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const long long* __restric
     }
     if (tid == 0) {
         cnt[b] = base_s;
-        atomicMax(tmax, base_s);
+        atomicMax(tmax + b / gsize, base_s);
     }
 }
 
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void gather_lerp_fwd_kernel(const float* __res
                                                               const int* __restrict__ idx, const int* __restrict__ cnt,
                                                               const int* __restrict__ tmax, float* __restrict__ out,
                                                               long long* __restrict__ mout, unsigned long long* __restrict__ lens,
-                                                              int Ta, int Tv, int D) {
+                                                              int Ta, int Tv, int D, int gsize) {
     const int i = blockIdx.x, b = blockIdx.y;
-    const int Tm = *tmax, n = cnt[b];
+    const int Tm = tmax[b / gsize], n = cnt[b];
     const LerpCoef c = lerp_coef(i, Tm, Tv);
     const bool ok0 = c.i0 < n, ok1 = c.i1 < n;
     const float* r0 = ok0 ? feat + ((long long)b * Ta + idx[(long long)b * Ta + c.i0]) * D : nullptr;
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256) void gather_lerp_fwd_kernel(const float* __res
 // dfeat[b][idx[j]][:] = sum_i w(i,j) dout[b][i][:]   (dfeat pre-zeroed; every source frame is written by one block)
 __global__ __launch_bounds__(256) void gather_lerp_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx,
                                                               const int* __restrict__ cnt, const int* __restrict__ tmax,
-                                                              float* __restrict__ dfeat, int Ta, int Tv, int D) {
+                                                              float* __restrict__ dfeat, int Ta, int Tv, int D, int gsize) {
     const int j = blockIdx.x, b = blockIdx.y;
-    const int Tm = *tmax, n = cnt[b];
+    const int Tm = tmax[b / gsize], n = cnt[b];
     if (j >= n) return;
     int lo, hi;
     if (Tm == Tv) { lo = j; hi = j; }
@@ -166,30 +166,35 @@ extern "C" int av_mask_downsample(const long long* mask, long long* out, int B, 
     return AV_OK;
 }
 
-// ws_i32: [B*Ta idx][B cnt][1 tmax] ints.  lens: int64 [B] (zeroed here).
+// ws_i32: [B*Ta idx][B cnt][groups tmax] ints.  lens: int64 [B] (zeroed here).  The "batch maximum" the reference pads
+// to is taken per group of B/groups consecutive items (groups = 1: the reference's per-call semantics; groups = 2 lets
+// the trainer push both speakers through one call without changing the result).
 extern "C" int av_fusion_gather_lerp_fwd(const float* feat, const long long* mask, int* ws_i32, float* out, long long* mask_out,
-                                         long long* lens, int B, int Ta, int Tv, int D, void* stream) {
+                                         long long* lens, int B, int Ta, int Tv, int D, int groups, void* stream) {
     AV_CHECK(feat && mask && ws_i32 && out && mask_out && lens, "av_fusion_gather_lerp_fwd: null pointer");
-    AV_CHECK(B > 0 && Ta > 0 && Tv > 0 && D > 0, "av_fusion_gather_lerp_fwd: bad shape");
+    AV_CHECK(B > 0 && Ta > 0 && Tv > 0 && D > 0 && groups >= 1 && B % groups == 0, "av_fusion_gather_lerp_fwd: bad shape (B=%d groups=%d)", B, groups);
     hipStream_t st = (hipStream_t)stream;
+    const int gsize = B / groups;
     int* idx = ws_i32; int* cnt = ws_i32 + (long long)B * Ta; int* tmax = cnt + B;
-    if (hipMemsetAsync(tmax, 0, sizeof(int), st) != hipSuccess || hipMemsetAsync(lens, 0, sizeof(long long) * B, st) != hipSuccess) {
+    if (hipMemsetAsync(tmax, 0, sizeof(int) * groups, st) != hipSuccess || hipMemsetAsync(lens, 0, sizeof(long long) * B, st) != hipSuccess) {
         av_set_error("av_fusion_gather_lerp_fwd: memset failed"); return AV_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, st, mask, idx, cnt, tmax, Ta);
+    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, st, mask, idx, cnt, tmax, Ta, gsize);
     AV_LAUNCH_CHECK();
     hipLaunchKernelGGL(gather_lerp_fwd_kernel, dim3(Tv, B), dim3(256), 0, st, feat, mask, idx, cnt, tmax, out, mask_out,
-                       (unsigned long long*)lens, Ta, Tv, D);
+                       (unsigned long long*)lens, Ta, Tv, D, gsize);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
 
-extern "C" int av_fusion_gather_lerp_bwd(const float* dout, const int* ws_i32, float* dfeat, int B, int Ta, int Tv, int D, void* stream) {
-    AV_CHECK(dout && ws_i32 && dfeat, "av_fusion_gather_lerp_bwd: null pointer");
+extern "C" int av_fusion_gather_lerp_bwd(const float* dout, const int* ws_i32, float* dfeat, int B, int Ta, int Tv, int D, int groups,
+                                         void* stream) {
+    AV_CHECK(dout && ws_i32 && dfeat && groups >= 1 && B % groups == 0, "av_fusion_gather_lerp_bwd: bad args");
+    const int gsize = B / groups;
     hipStream_t st = (hipStream_t)stream;
     const int* idx = ws_i32; const int* cnt = ws_i32 + (long long)B * Ta; const int* tmax = cnt + B;
     if (hipMemsetAsync(dfeat, 0, sizeof(float) * (size_t)B * Ta * D, st) != hipSuccess) { av_set_error("av_fusion_gather_lerp_bwd: memset failed"); return AV_ERR_LAUNCH; }
-    hipLaunchKernelGGL(gather_lerp_bwd_kernel, dim3(Ta, B), dim3(256), 0, st, dout, idx, cnt, tmax, dfeat, Ta, Tv, D);
+    hipLaunchKernelGGL(gather_lerp_bwd_kernel, dim3(Ta, B), dim3(256), 0, st, dout, idx, cnt, tmax, dfeat, Ta, Tv, D, gsize);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

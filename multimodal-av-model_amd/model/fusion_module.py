@@ -117,7 +117,7 @@ def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: D
 
 class _FusionFn(torch.autograd.Function):
     @staticmethod
-    def forward(fctx, mod: "CrossAttentionFusion", save: bool, names, visual_feat, audio_feat, mask, *params):
+    def forward(fctx, mod: "CrossAttentionFusion", save: bool, names, groups: int, visual_feat, audio_feat, mask, *params):
         dtype = compute_dtype()
         dev = audio_feat.device
         E, nh = mod.fused_dim, mod.num_heads
@@ -126,12 +126,12 @@ class _FusionFn(torch.autograd.Function):
         _, Ta, Da = audio_feat.shape
         af = audio_feat.contiguous().float()
         mask = mask.contiguous().long()
-        ws = torch.empty(B * Ta + B + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(B * Ta + B + groups, dtype=torch.int32, device=dev)
         a_in = torch.empty((B, Tv, Da), dtype=torch.float32, device=dev)
         m_out = torch.empty((B, Tv), dtype=torch.long, device=dev)
         lens = torch.empty((B,), dtype=torch.long, device=dev)
         L.check(L.lib().av_fusion_gather_lerp_fwd(ops.ptr(af), ops.ptr(mask), ops.ptr(ws), ops.ptr(a_in), ops.ptr(m_out), ops.ptr(lens),
-                                                  B, Ta, Tv, Da, ops.stream()), "av_fusion_gather_lerp_fwd")
+                                                  B, Ta, Tv, Da, groups, ops.stream()), "av_fusion_gather_lerp_fwd")
         c = lambda p: mod.cparam(p, dtype)
         vis_t = ops.cast(visual_feat.contiguous().float(), dtype)
         a_in_t = ops.cast(a_in, dtype)
@@ -152,7 +152,7 @@ class _FusionFn(torch.autograd.Function):
         out = ops.cast(out_bt, torch.float32)
         if save:
             fctx.saved = dict(ws=ws, vis_t=vis_t, a_in_t=a_in_t, v=v, a=a, q=q, kv=kv, o=o, a2v=a2v, fused=fused, lstm=lctx,
-                              shape=(B, Tv, Ta, Da, Dv), dtype=dtype)
+                              shape=(B, Tv, Ta, Da, Dv), dtype=dtype, groups=groups)
         else:
             fctx.saved = None
         fctx.mod, fctx.names = mod, names
@@ -164,7 +164,7 @@ class _FusionFn(torch.autograd.Function):
     @staticmethod
     def backward(fctx, dout, _dl, _dm):
         mod, s = fctx.mod, fctx.saved
-        n_extra = 6
+        n_extra = 7
         if s is None:
             return (None,) * (n_extra + len(fctx.names))
         B, Tv, Ta, Da, Dv = s["shape"]
@@ -201,12 +201,12 @@ class _FusionFn(torch.autograd.Function):
         if fctx.need_audio:
             da_in = ops.matmul_nn(da, c(mod.audio_proj.weight), out_dtype=torch.float32)       # [M, Da]
             d_audio = torch.empty((B, Ta, Da), dtype=torch.float32, device=dout.device)
-            L.check(L.lib().av_fusion_gather_lerp_bwd(ops.ptr(da_in), ops.ptr(s["ws"]), ops.ptr(d_audio), B, Ta, Tv, Da, ops.stream()),
+            L.check(L.lib().av_fusion_gather_lerp_bwd(ops.ptr(da_in), ops.ptr(s["ws"]), ops.ptr(d_audio), B, Ta, Tv, Da, s["groups"], ops.stream()),
                     "av_fusion_gather_lerp_bwd")
         if fctx.need_visual:
             d_visual = ops.matmul_nn(dv, c(mod.visual_proj.weight), out_dtype=torch.float32).view(B, Tv, Dv)
         fctx.saved = None
-        return (None, None, None, d_visual, d_audio, None) + tuple(g.get(n) for n in fctx.names)
+        return (None, None, None, None, d_visual, d_audio, None) + tuple(g.get(n) for n in fctx.names)
 
 
 class CrossAttentionFusion(nn.Module):
@@ -229,9 +229,11 @@ class CrossAttentionFusion(nn.Module):
             return p.data
         return self._cache.get(("c", id(p)), [p], dtype, lambda: ops.cast(p.data.contiguous(), dtype))
 
-    def forward(self, visual_feat, audio_feat, mask=None):
+    def forward(self, visual_feat, audio_feat, mask=None, groups: int = 1):
         """visual_feat [B,T_v,D_v], audio_feat [B,T_a,D_a], mask [B,T_a] (0/3 ignore, 1/2 use) ->
-        (fused [B,T_v,2*fused_dim], input_lengths int64 [B] on mask.device)"""
+        (fused [B,T_v,2*fused_dim], input_lengths int64 [B] on mask.device).
+        ``groups`` (extension): the batch holds ``groups`` independent calls stacked along dim 0; the reference's
+        "pad to the batch maximum" (:46) is then evaluated per group, so the result equals ``groups`` separate calls."""
         if mask is None:
             raise ValueError("CrossAttentionFusion: mask is required (the reference dereferences it unconditionally, :66)")
         if not audio_feat.is_cuda:
@@ -239,6 +241,6 @@ class CrossAttentionFusion(nn.Module):
         names = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("cross_attn_visual.")]
         params = [dict(self.named_parameters())[n] for n in names]
         save = torch.is_grad_enabled() and (bool(names) or audio_feat.requires_grad or visual_feat.requires_grad)
-        out, lens, m_out = _FusionFn.apply(self, save, names, visual_feat, audio_feat, mask, *params)
+        out, lens, m_out = _FusionFn.apply(self, save, names, groups, visual_feat, audio_feat, mask, *params)
         self.last_mask = m_out
         return out, lens

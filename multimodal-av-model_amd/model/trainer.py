@@ -43,7 +43,8 @@ def word_error_rate(refs, hyps) -> float:
 
 class MultimodalTrainer:
     def __init__(self, visual_encoder, audio_encoder, fusion_module, decoder1, tokenizer, learning_rate=1e-4, device="cuda",
-                 lambda_=0.1, audio_passes: int = 1, reducer: Optional[GradBucketReducer] = None):
+                 lambda_=0.1, audio_passes: int = 1, reducer: Optional[GradBucketReducer] = None, pair_batched: bool = True,
+                 visual_side_stream: bool = True):
         self.visual_encoder = visual_encoder.to(device)
         self.audio_encoder = audio_encoder.to(device)
         self.fusion_module = fusion_module.to(device)
@@ -52,6 +53,12 @@ class MultimodalTrainer:
         self.device = device
         self.lambda_ = lambda_
         self.audio_passes = audio_passes
+        # both speakers go through fusion / BiLSTM / CTC head as ONE 2B batch (items are independent there, so results are
+        # identical; it halves the number of latency-bound LSTM step launches), and the frozen visual encoder runs on a
+        # side stream concurrently with the wav2vec2 forward
+        self.pair_batched = pair_batched
+        self.visual_side_stream = visual_side_stream
+        self._vstream = None
         self.ctc_loss = nn.CTCLoss(blank=tokenizer.blank_id, zero_infinity=True)       # stays on PyTorch-ROCm
         self.parameters = (list(self.visual_encoder.parameters()) + list(self.audio_encoder.parameters())
                            + list(self.fusion_module.parameters()) + list(self.decoder1.parameters()))
@@ -101,8 +108,18 @@ class MultimodalTrainer:
     def forward_losses(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """model/trainer.py:66-119 for one batch; everything stays on the device."""
         d = self._to_dev(batch)
-        vf1 = self.visual_encoder(d["lip1"])
-        vf2 = self.visual_encoder(d["lip2"])
+        use_side = self.visual_side_stream and d["audio"].is_cuda
+        if use_side:
+            if self._vstream is None:
+                self._vstream = torch.cuda.Stream(device=d["audio"].device)
+            main = torch.cuda.current_stream(d["audio"].device)
+            self._vstream.wait_stream(main)
+            with torch.cuda.stream(self._vstream):
+                vf1 = self.visual_encoder(d["lip1"])
+                vf2 = self.visual_encoder(d["lip2"])
+        else:
+            vf1 = self.visual_encoder(d["lip1"])
+            vf2 = self.visual_encoder(d["lip2"])
         attn1 = d["mask1"] != 3
         a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1)
         if self.audio_passes == 2:
@@ -125,10 +142,19 @@ class MultimodalTrainer:
             c2 = contrastive_loss_with_mask(mid2, m2.reshape(-1), self.projection_layer, counts=k2)
         else:
             c1 = c2 = torch.zeros((), device=a1.device)
-        f1, il1 = self.fusion_module(vf1, a1, mask=m1)
-        f2, il2 = self.fusion_module(vf2, a2, mask=m2)
-        lp1 = self.decoder1(f1)
-        lp2 = self.decoder1(f2)
+        if use_side:
+            main.wait_stream(self._vstream)
+            vf1.record_stream(main); vf2.record_stream(main)
+        B = a1.shape[0]
+        if self.pair_batched:
+            f12, il12 = self.fusion_module(torch.cat([vf1, vf2], 0), torch.cat([a1, a2], 0), mask=torch.cat([m1, m2], 0), groups=2)
+            lp12 = self.decoder1(f12)
+            f1, f2, il1, il2, lp1, lp2 = f12[:B], f12[B:], il12[:B], il12[B:], lp12[:B], lp12[B:]
+        else:
+            f1, il1 = self.fusion_module(vf1, a1, mask=m1)
+            f2, il2 = self.fusion_module(vf2, a2, mask=m2)
+            lp1 = self.decoder1(f1)
+            lp2 = self.decoder1(f2)
         l1 = self.ctc_loss(lp1.transpose(0, 1), d["text1"], il1, d["text1_lengths"])
         l2 = self.ctc_loss(lp2.transpose(0, 1), d["text2"], il2, d["text2_lengths"])
         total = (l1 + l2) / 2 + self.lambda_ * (c1 + c2) / 2

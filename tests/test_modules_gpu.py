@@ -162,3 +162,25 @@ def test_adam_step_matches_torch():
         opt.step()
         L.check(L.lib().av_adam_step(ops.ptr(pc), ops.ptr(gr.cuda()), ops.ptr(m), ops.ptr(v), pc.numel(), 2e-5, 0.9, 0.999, 1e-8, step, 1.0, ops.stream()))
     torch.testing.assert_close(pc.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_fusion_groups_equals_separate_calls():
+    """Pair-batched call (groups=2) == two per-speaker calls: the 'batch maximum' is evaluated per group."""
+    _p("fp32")
+    init = pkg("utils.init"); fm = pkg("model.fusion_module")
+    B, Tv, Ta, Da = 3, 25, 49, 64
+    g = torch.Generator().manual_seed(11)
+    vis1, vis2 = torch.randn(B, Tv, 512, generator=g).cuda(), torch.randn(B, Tv, 512, generator=g).cuda()
+    aud = torch.randn(B, Ta, Da, generator=g).cuda()
+    m1 = torch.ones(B, Ta, dtype=torch.long); m1[:, 36:] = 2
+    m2 = torch.ones(B, Ta, dtype=torch.long); m2[:, 36:] = 0            # speaker 2 keeps only 36 frames -> different batch max
+    m1, m2 = m1.cuda(), m2.cuda()
+    mod = fm.CrossAttentionFusion(512, Da, 512).cuda(); mod.load_state_dict(init.fusion_state_dict(512, Da, 512))
+    with torch.no_grad():
+        o1, l1 = mod(vis1, aud, m1); o2, l2 = mod(vis2, aud, m2)
+        o12, l12 = mod(torch.cat([vis1, vis2]), torch.cat([aud, aud]), torch.cat([m1, m2]), groups=2)
+    assert torch.equal(l12, torch.cat([l1, l2]))
+    torch.testing.assert_close(o12, torch.cat([o1, o2]), rtol=1e-5, atol=1e-5)
+    with torch.no_grad():
+        bad, _ = mod(torch.cat([vis1, vis2]), torch.cat([aud, aud]), torch.cat([m1, m2]), groups=1)
+    assert float((bad[B:] - o2).abs().max()) > 1e-3      # without groups the second speaker would be resampled differently
