@@ -102,12 +102,11 @@ def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: D
         grads["temporal_model." + n[5]] = db[4 * H:]; grads["temporal_model." + n[7]] = db[4 * H:]
         dwhh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
         if T > 1:
-            K = (T - 1) * B
-            # forward chain: dgates[t] pairs with h[t-1]; reverse chain: dgates[t] pairs with h[t+1]
-            ops.gemm(dgates, hseq, dwhh, M=4 * H, N=H, K=K, lda=8 * H, ldb=2 * H, ldc=H, a_mode=L.A_TRANS, b_mode=L.B_KN,
-                     a_off=B * 8 * H, b_off=0, c_off=0)
-            ops.gemm(dgates, hseq, dwhh, M=4 * H, N=H, K=K, lda=8 * H, ldb=2 * H, ldc=H, a_mode=L.A_TRANS, b_mode=L.B_KN,
-                     a_off=4 * H, b_off=B * 2 * H + H, c_off=4 * H * H)
+            # forward chain: dgates[t] pairs with h[t-1]; reverse chain: dgates[t] pairs with h[t+1].  Time-major buffers
+            # make the one-step shift a row offset of B; the column slices are transposed to the K-contiguous fast form.
+            h2 = hseq.view(M, 2 * H)
+            ops.matmul_tn(dg2[B:, :4 * H], h2[:M - B, :H], out=dwhh[0])
+            ops.matmul_tn(dg2[:M - B, 4 * H:], h2[B:, H:], out=dwhh[1])
         grads["temporal_model." + n[2]] = dwhh[0]
         grads["temporal_model." + n[3]] = dwhh[1]
         dx = ops.matmul_nn(dg2, c["wih"], out_dtype=dtype).view(T, B, in_f)              # time-major

@@ -162,10 +162,11 @@ def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, 
 
 
 def matmul_tn(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, alpha: float = 1.0, accumulate: bool = False) -> Tensor:
-    """y[M,N] (fp32) = a[K,M]^T @ b[K,N]   (dW = dY^T X: a = dY [tokens, out], b = X [tokens, in])."""
+    """y[M,N] (fp32) = a[K,M]^T @ b[K,N]   (dW = dY^T X: a = dY [tokens, out], b = X [tokens, in]).
+    a / b may be row-strided views (last dim contiguous)."""
     Kk, M = a.shape
     N = b.shape[1]
-    assert b.shape[0] == Kk and a.is_contiguous() and b.is_contiguous()
+    assert b.shape[0] == Kk and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     if _fast_ok(a, Kk, N) and M > 64:
@@ -174,7 +175,7 @@ def matmul_tn(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, alpha: floa
         Kp = at.shape[1]
         gemm(at, bt, out, M=M, N=N, K=Kp, lda=Kp, ldb=Kp, ldc=N, alpha=alpha, R=out if accumulate else None)
         return out
-    gemm(a, b, out, M=M, N=N, K=Kk, lda=M, ldb=N, ldc=N, a_mode=L.A_TRANS, b_mode=L.B_KN, alpha=alpha,
+    gemm(a, b, out, M=M, N=N, K=Kk, lda=a.stride(0), ldb=b.stride(0), ldc=N, a_mode=L.A_TRANS, b_mode=L.B_KN, alpha=alpha,
          R=out if accumulate else None)
     return out
 
