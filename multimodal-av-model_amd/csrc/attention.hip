@@ -238,6 +238,7 @@ int dispatch_d(const AttnP& p, int D, hipStream_t st) {
 // ---- rows of the unfused backward -------------------------------------------------------------------------
 constexpr int MAXIT = 32;
 // P[row][:] = softmax(scale*S[row][:klen]) (0 beyond klen); rows are [b][h][tq]
+template <int NIT>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, void* __restrict__ pout, int pdt, long long rows,
                                                            int cols, float scale, const int* __restrict__ klen, int rows_per_batch, int ld) {
     const int lane = threadIdx.x & 63;
@@ -247,10 +248,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     if (kl > cols) kl = cols;
     if (kl < 1) kl = 1;
     const long long base = row * ld;
-    float v[MAXIT];
+    float v[NIT];
     float mx = -INFINITY;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = lane + 64 * it;
         v[it] = c < kl ? s[base + c] * scale : -INFINITY;
         mx = fmaxf(mx, v[it]);
@@ -258,29 +259,30 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         v[it] = expf(v[it] - mx);
         sum += v[it];
     }
     const float inv = 1.0f / wave_sum(sum);
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = lane + 64 * it;
         if (c < cols) st_any(pout, base + c, pdt, v[it] * inv);
     }
 }
 
 // dS = scale * P o (dP - sum(dP o P))
+template <int NIT>
 __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const void* __restrict__ pm, int pdt, const float* __restrict__ dp,
                                                                void* __restrict__ ds, int dsdt, long long rows, int cols, float scale, int ld) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const long long base = row * ld;
-    float pv[MAXIT], dv[MAXIT];
+    float pv[NIT], dv[NIT];
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = lane + 64 * it;
         pv[it] = c < cols ? ld_any(pm, base + c, pdt) : 0.f;
         dv[it] = c < cols ? dp[base + c] : 0.f;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const void* __res
     }
     s = wave_sum(s);
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = lane + 64 * it;
         if (c < cols) st_any(ds, base + c, dsdt, scale * pv[it] * (dv[it] - s));
     }
@@ -321,8 +323,9 @@ extern "C" int av_softmax_rows(const float* s, void* p, int pdt, long long rows,
     AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_softmax_rows: cols=%d out of range (1..%d)", cols, 64 * MAXIT);
     AV_CHECK(rows_per_batch > 0, "av_softmax_rows: rows_per_batch=%d", rows_per_batch);
     if (rows == 0) return AV_OK;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, p, pdt, rows, cols,
-                       scale, klen, rows_per_batch, ld);
+#define SMR(N) hipLaunchKernelGGL((softmax_rows_kernel<N>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, p, pdt, rows, cols, scale, klen, rows_per_batch, ld)
+    if (cols <= 64) SMR(1); else if (cols <= 128) SMR(2); else if (cols <= 256) SMR(4); else if (cols <= 512) SMR(8); else if (cols <= 1024) SMR(16); else SMR(32);
+#undef SMR
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -332,8 +335,9 @@ extern "C" int av_softmax_bwd_rows(const void* p, int pdt, const float* dp, void
     AV_CHECK(p && dp && ds, "av_softmax_bwd_rows: null pointer");
     AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_softmax_bwd_rows: cols=%d out of range", cols);
     if (rows == 0) return AV_OK;
-    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, pdt, dp, ds,
-                       dsdt, rows, cols, scale, ld);
+#define SMB(N) hipLaunchKernelGGL((softmax_bwd_rows_kernel<N>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, pdt, dp, ds, dsdt, rows, cols, scale, ld)
+    if (cols <= 64) SMB(1); else if (cols <= 128) SMB(2); else if (cols <= 256) SMB(4); else if (cols <= 512) SMB(8); else if (cols <= 1024) SMB(16); else SMB(32);
+#undef SMB
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -54,14 +54,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
     for (int oyt = 0; oyt < ntile; ++oyt) {
         const int oy0 = oyt * TOY;
         __syncthreads();                                        // previous tile's image reads are done
-        for (int i = tid; i < KT * PH * PW; i += 256) {
-            const int px = i % PW, q = i / PW;
+        for (int i = tid; i < KT * PH * (PW / 4); i += 256) {       // 4 consecutive patch pixels per thread
+            const int pc = i % (PW / 4), q = i / (PW / 4);
             const int py = q % PH, kt = q / PH;
-            const int ti = t + kt - 2, iy = 2 * oy0 - 3 + py, ix = 2 * ox0 - 3 + px;
-            float v = 0.f;
-            if (ti >= 0 && ti < p.T && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = p.x[((long long)(bt + kt - 2) * p.H + iy) * p.W + ix];
-            patch[i] = (bf16_t)v;
+            const int ti = t + kt - 2, iy = 2 * oy0 - 3 + py, ix0 = 2 * ox0 - 3 + pc * 4;
+            const bool rowok = ti >= 0 && ti < p.T && iy >= 0 && iy < p.H;
+            const float* src = p.x + ((long long)(bt + kt - 2) * p.H + iy) * p.W;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ix = ix0 + e;
+                o[e] = (bf16_t)((rowok && ix >= 0 && ix < p.W) ? src[ix] : 0.f);
+            }
+            *(bf16x4*)(patch + (kt * PH + py) * PW + pc * 4) = o;
         }
         __syncthreads();
         f32x4 acc[2][4];
@@ -103,11 +108,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
             for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v0[e]; o[4 + e] = (bf16_t)v1[e]; }
             *(bf16x8*)(p.y + (((long long)bt * p.Ho + oy) * p.Wo + ox) * 64 + cc) = o;
         }
-        if (p.stats && tid < 64) {
+        if (p.stats) {                                           // 4 row groups x 64 columns, combined through LDS
+            const int c = tid & 63, rg = tid >> 6;
             float s1 = 0.f, s2 = 0.f;
-            for (int rr = 0; rr < 128; ++rr) { const float v = cs[rr * CLD + tid]; s1 += v; s2 += v * v; }
-            float* o = p.stats + (((long long)bt * ntile + oyt) * gridDim.x + oxt) * 128;
-            o[tid] = s1; o[64 + tid] = s2;
+            for (int rr = rg * 32; rr < rg * 32 + 32; ++rr) { const float v = cs[rr * CLD + c]; s1 += v; s2 += v * v; }
+            __syncthreads();                                    // image reads of the store loop are done
+            float* red = cs;                                    // reuse the image: [4][2][64]
+            red[(rg * 2 + 0) * 64 + c] = s1; red[(rg * 2 + 1) * 64 + c] = s2;
+            __syncthreads();
+            if (tid < 128) {
+                const int which = tid >> 6;
+                float* o = p.stats + (((long long)bt * ntile + oyt) * gridDim.x + oxt) * 128;
+                o[which * 64 + c] = red[(0 * 2 + which) * 64 + c] + red[(1 * 2 + which) * 64 + c] + red[(2 * 2 + which) * 64 + c] + red[(3 * 2 + which) * 64 + c];
+            }
         }
     }
 }

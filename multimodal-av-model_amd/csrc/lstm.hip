@@ -44,14 +44,14 @@ __device__ __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) 
 // accumulates a quarter of K for all row tiles, partials meet in LDS, wave w finishes row tile w.
 constexpr int MAXMT = 4;   // 64 rows per workgroup (blockIdx.z selects the 64-row group)
 
-template <typename T>
+template <typename T, int HT>
 __global__ __launch_bounds__(256) void lstm_fwd_step(const LstmFwdP p) {
     constexpr int KS = Frag<T>::KS, PER = Frag<T>::PER;
     __shared__ float red[4][MAXMT][4][4][64];        // [wave][row tile][gate][acc reg][lane]  (64 KiB)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int d = blockIdx.y, j0 = blockIdx.x * 16, mbase = blockIdx.z * 64;
-    const int H = p.H, B = p.B;
+    const int H = HT > 0 ? HT : p.H, B = p.B;
     const int td = d == 0 ? p.s : p.T - 1 - p.s;           // time handled by this direction
     const int tp = d == 0 ? td - 1 : td + 1;               // previous time of the chain
     int nmt = (B - mbase + 15) / 16;
@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_step(const LstmFwdP p) {
         const T* hprev = (const T*)p.hseq + ((long long)tp * B) * 2 * H + d * H;          // row stride 2H
         const T* W = (const T*)p.whh + (long long)d * 4 * H * H;
         const int kq = H / 4;
-        for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += KS) {
+#pragma unroll
+        for (int kk = 0; kk < (HT > 0 ? HT / 4 / KS : 1 << 20); ++kk) {
+            const int k0 = w * kq + kk * KS;
+            if (HT == 0 && k0 >= (w + 1) * kq) break;
             typename Frag<T>::type b[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) b[q] = ld_frag<T>(W + (long long)(q * H + j0 + r) * H + k0 + PER * g, true);
@@ -129,14 +132,14 @@ struct LstmBwdP {
     int T, B, H, s;
 };
 
-template <typename T>
+template <typename T, int HT>
 __global__ __launch_bounds__(256) void lstm_bwd_step(const LstmBwdP p) {
     constexpr int KS = Frag<T>::KS, PER = Frag<T>::PER;
     __shared__ float red[4][MAXMT][4][64];           // [wave][row tile][acc reg][lane]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int d = blockIdx.y, j0 = blockIdx.x * 16, mbase = blockIdx.z * 64;
-    const int H = p.H, B = p.B;
+    const int H = HT > 0 ? HT : p.H, B = p.B;
     const int td = d == 0 ? p.T - 1 - p.s : p.s;           // backward visits the chain in reverse
     const int tn = d == 0 ? td + 1 : td - 1;               // time handled at the previous backward step
     const int tp = d == 0 ? td - 1 : td + 1;               // forward-previous time (c_prev)
@@ -150,7 +153,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step(const LstmBwdP p) {
         const T* Wt = (const T*)p.whhT + (long long)d * H * 4 * H;
         const T* bp = Wt + (long long)(j0 + r) * 4 * H + PER * g;
         const int kq = H;                                   // 4H / 4
-        for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += KS) {
+#pragma unroll
+        for (int kk = 0; kk < (HT > 0 ? HT / KS : 1 << 20); ++kk) {
+            const int k0 = w * kq + kk * KS;
+            if (HT == 0 && k0 >= (w + 1) * kq) break;
             const auto b = ld_frag<T>(bp + k0, true);
 #pragma unroll
             for (int mt = 0; mt < MAXMT; ++mt) {
@@ -203,8 +209,9 @@ extern "C" int av_lstm_fwd_step(const float* gx, const void* whh, void* hseq, fl
     AV_CHECK(dtype == AV_F32 || dtype == AV_BF16, "av_lstm_fwd_step: bad dtype %d", dtype);
     LstmFwdP p{gx, whh, hseq, cseq, gates, out_bt, T, B, H, s};
     dim3 grid((unsigned)(H / 16), 2, (unsigned)((B + 63) / 64));
-    if (dtype == AV_F32) hipLaunchKernelGGL(lstm_fwd_step<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(lstm_fwd_step<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (dtype == AV_F32) hipLaunchKernelGGL((lstm_fwd_step<float, 0>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (H == 512) hipLaunchKernelGGL((lstm_fwd_step<bf16_t, 512>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((lstm_fwd_step<bf16_t, 0>), grid, dim3(256), 0, (hipStream_t)stream, p);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -216,8 +223,9 @@ extern "C" int av_lstm_bwd_step(const void* dout, int dout_dtype, long long do_b
     AV_CHECK(dtype == AV_F32 || dtype == AV_BF16, "av_lstm_bwd_step: bad dtype %d", dtype);
     LstmBwdP p{dout, dout_dtype, do_bs, do_ts, dgates, whhT, gates, cseq, dc, T, B, H, s};
     dim3 grid((unsigned)(H / 16), 2, (unsigned)((B + 63) / 64));
-    if (dtype == AV_F32) hipLaunchKernelGGL(lstm_bwd_step<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(lstm_bwd_step<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (dtype == AV_F32) hipLaunchKernelGGL((lstm_bwd_step<float, 0>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (H == 512) hipLaunchKernelGGL((lstm_bwd_step<bf16_t, 512>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((lstm_bwd_step<bf16_t, 0>), grid, dim3(256), 0, (hipStream_t)stream, p);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
