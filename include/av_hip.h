@@ -102,7 +102,13 @@ int av_mul_scalar_dev(const float* x, const float* scalar, float* y, long long n
 int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H, int Tq,
                      int Tk, int D, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
                      long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, void* stream);
-/* rows of the attention backward: P = softmax(scale*S) with key mask; dS = scale * P o (dP - sum(dP o P)) */
+/* fused (flash-style) attention backward, bf16: recomputes P from Q, K and the forward's LSE; dq/dk/dv written in place.
+ * strides[16] = (batch stride, row stride) of q, k, v, o, dout, dq, dk, dv (elements; head stride = D);
+ * delta_ws: B*H*Tq floats of workspace.  Backward of hf:438-463 / fusion_module.py:61. */
+int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                     float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int D,
+                     const long long* strides, const int* klen, float scale, void* stream);
+/* rows of the (unfused, fp32 parity mode) attention backward: P = softmax(scale*S) with key mask; dS = scale * P o (dP - sum(dP o P)) */
 int av_softmax_rows(const float* s, void* p, int pdt, long long rows, int cols, float scale, const int* klen,
                     int rows_per_batch, int ld, void* stream);
 int av_softmax_bwd_rows(const void* p, int pdt, const float* dp, void* ds, int dsdt, long long rows, int cols,

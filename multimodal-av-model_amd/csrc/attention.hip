@@ -7,97 +7,9 @@
 // / row sum of the softmax are reduced with wavefront shuffles inside each 16-lane group (the S accumulator has
 // the key on the lane).  P goes through a per-wave LDS tile to become the A operand of PV.
 // Also here: the row kernels of the (unfused) backward: softmax rows and its gradient.
-#include "av_common.h"
+#include "attn_common.h"
 
 namespace {
-
-template <typename T> struct ACfg;
-template <> struct ACfg<float> { static constexpr int VEC = 4; };
-template <> struct ACfg<bf16_t> { static constexpr int VEC = 8; };
-
-struct AttnP {
-    const void *q, *k, *v;
-    void* o;
-    float* lse;
-    const int* klen;
-    int B, H, Tq, Tk;
-    long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
-    float scale;
-    int vec_ok;
-};
-
-template <typename T> __device__ __forceinline__ void zero16(T* dst) { *(uint4*)dst = make_uint4(0, 0, 0, 0); }
-
-// acc += A[16 x K] * B[16 x K]^T, both operands row-major in LDS with K contiguous
-template <typename T>
-__device__ __forceinline__ void mma_rows(f32x4& acc, const T* a, int lda, const T* b, int ldb, int K, int lane);
-template <>
-__device__ __forceinline__ void mma_rows<bf16_t>(f32x4& acc, const bf16_t* a, int lda, const bf16_t* b, int ldb, int K, int lane) {
-    const int r = lane & 15, g = lane >> 4;
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        const bf16x8 av = *(const bf16x8*)(a + r * lda + k0 + 8 * g);
-        const bf16x8 bv = *(const bf16x8*)(b + r * ldb + k0 + 8 * g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
-    }
-}
-template <>
-__device__ __forceinline__ void mma_rows<float>(f32x4& acc, const float* a, int lda, const float* b, int ldb, int K, int lane) {
-    const int r = lane & 15, g = lane >> 4;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const f32x4 av = *(const f32x4*)(a + r * lda + k0 + 4 * g);
-        const f32x4 bv = *(const f32x4*)(b + r * ldb + k0 + 4 * g);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[jj], acc, 0, 0, 0);
-    }
-}
-
-// stage `rows_tile` x DK elements (zero-filled outside [row_end) x [0,D)) into dst[row][ld]
-template <typename T, int D, int DK>
-__device__ __forceinline__ void stage_rows(T* dst, int ld, const T* src, long long rs, int row0, int row_end, bool vec, int tid) {
-    constexpr int VEC = ACfg<T>::VEC;
-    constexpr int CPR = DK / VEC;
-    for (int c = tid; c < 64 * CPR; c += 256) {
-        const int row = c / CPR, col = (c % CPR) * VEC;
-        const int gr = row0 + row;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gr < row_end && col < D) {
-            const T* p = src + (long long)gr * rs + col;
-            if (vec) v = *(const uint4*)p;
-            else {
-                __attribute__((aligned(16))) T tmp[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) tmp[e] = p[e];
-                v = *(const uint4*)tmp;
-            }
-        }
-        *(uint4*)(dst + row * ld + col) = v;
-    }
-}
-
-// stage V rows [row0,row0+64) transposed: dst[d][key]
-template <typename T, int D>
-__device__ __forceinline__ void stage_vt(T* dst, int ld, const T* src, long long rs, int row0, int row_end, bool vec, int tid) {
-    constexpr int VEC = ACfg<T>::VEC;
-    constexpr int CPR = D / VEC;
-    for (int c = tid; c < 64 * CPR; c += 256) {
-        const int key = c / CPR, col = (c % CPR) * VEC;
-        const int gr = row0 + key;
-        __attribute__((aligned(16))) T tmp[VEC];
-        if (gr < row_end) {
-            const T* p = src + (long long)gr * rs + col;
-            if (vec) *(uint4*)tmp = *(const uint4*)p;
-            else {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) tmp[e] = p[e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(0.f);
-        }
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) dst[(col + e) * ld + key] = tmp[e];
-    }
-}
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {

@@ -1,0 +1,262 @@
+// Fused (flash-style) attention backward for the bf16 perf path: P is recomputed from Q, K and the forward's LSE, the
+// T x T score matrices never reach HBM.  Backward of hf:438-463 (sdpa) and of nn.MultiheadAttention's core.
+//   delta[q]  = sum_d dO[q][d] O[q][d]
+//   P         = exp(scale * Q K^T - LSE[q])      (0 for masked keys)
+//   dV       += P^T dO ;   dP = dO V^T ;   dS = scale * P o (dP - delta[q]) ;   dQ += dS K ;   dK += dS^T Q
+// Two kernels so that no accumulation crosses workgroups (no atomics, bitwise reproducible):
+//   attn_bwd_kv : one workgroup = 64 keys of a (batch, head); each wave keeps dK, dV of 16 keys in accumulators and
+//                 sweeps the query tiles.  S^T and dP^T are computed with the KEY on the accumulator row, so that P^T
+//                 and dS^T only need the per-wave LDS round trip to become A operands of the dV / dK products.
+//   attn_bwd_q  : one workgroup = 64 queries; each wave keeps dQ of 16 rows and sweeps the key tiles.
+// Operands are staged row-major AND (where they are the B operand of a product over the token axis) transposed in LDS.
+#include "attn_common.h"
+
+namespace {
+
+struct BwdP {
+    const bf16_t *q, *k, *v, *dout;
+    const float *lse, *delta;
+    bf16_t *dq, *dk, *dv;
+    const int* klen;
+    int B, H, Tq, Tk;
+    long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    float scale;
+    int vec_ok;
+};
+
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, int B, int H,
+                                  int T, int D, long long o_bs, long long o_rs, long long do_bs, long long do_rs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // (b, h, t)
+    if (i >= (long long)B * H * T) return;
+    const int t = (int)(i % T);
+    const int h = (int)((i / T) % H);
+    const int b = (int)(i / ((long long)T * H));
+    const bf16_t* po = o + (long long)b * o_bs + (long long)t * o_rs + (long long)h * D;
+    const bf16_t* pd = dout + (long long)b * do_bs + (long long)t * do_rs + (long long)h * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += (float)po[d] * (float)pd[d];
+    delta[i] = s;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const BwdP p) {
+    typedef bf16_t T;
+    constexpr int DK = (D + 31) / 32 * 32, DN = D / 16;
+    constexpr int LDK = DK + 8, LDT = 64 + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ks = (T*)smem;                 // [64][LDK]   keys of this workgroup
+    T* Vs = Ks + 64 * LDK;            // [64][LDK]
+    T* Qs = Vs + 64 * LDK;            // [64][LDK]   current query tile
+    T* Os = Qs + 64 * LDK;            // [64][LDK]   dO tile
+    T* Qt = Os + 64 * LDK;            // [D][LDT]    Q^T  (B operand of dK)
+    T* Ot = Qt + D * LDT;             // [D][LDT]    dO^T (B operand of dV)
+    T* Pw = Ot + D * LDT;             // [4][16][LDT]  P^T  per wave
+    T* Sw = Pw + 4 * 16 * LDT;        // [4][16][LDT]  dS^T per wave
+    float* lse_s = (float*)(Sw + 4 * 16 * LDT);   // [64]
+    float* del_s = lse_s + 64;                    // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int j0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const bool vec = p.vec_ok != 0;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+    const T* Q = p.q + (long long)b * p.q_bs + (long long)h * D;
+    const T* K = p.k + (long long)b * p.k_bs + (long long)h * D;
+    const T* V = p.v + (long long)b * p.v_bs + (long long)h * D;
+    const T* DO = p.dout + (long long)b * p.do_bs + (long long)h * D;
+    const float* lse = p.lse + ((long long)b * p.H + h) * p.Tq;
+    const float* del = p.delta + ((long long)b * p.H + h) * p.Tq;
+
+    stage_rows<T, D, DK>(Ks, LDK, K, p.k_rs, j0, p.Tk, vec, tid);
+    stage_rows<T, D, DK>(Vs, LDK, V, p.v_rs, j0, p.Tk, vec, tid);
+
+    f32x4 dKa[DN], dVa[DN];
+#pragma unroll
+    for (int n = 0; n < DN; ++n) { dKa[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dVa[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    T* Pme = Pw + w * 16 * LDT;
+    T* Sme = Sw + w * 16 * LDT;
+    const T* Kme = Ks + w * 16 * LDK;
+    const T* Vme = Vs + w * 16 * LDK;
+
+    for (int i0 = 0; i0 < p.Tq; i0 += 64) {
+        __syncthreads();                                            // previous tile's operands are no longer read
+        stage_rows<T, D, DK>(Qs, LDK, Q, p.q_rs, i0, p.Tq, vec, tid);
+        stage_rows<T, D, DK>(Os, LDK, DO, p.do_rs, i0, p.Tq, vec, tid);
+        stage_vt<T, D>(Qt, LDT, Q, p.q_rs, i0, p.Tq, vec, tid);
+        stage_vt<T, D>(Ot, LDT, DO, p.do_rs, i0, p.Tq, vec, tid);
+        if (tid < 64) {
+            const int qq = i0 + tid;
+            lse_s[tid] = qq < p.Tq ? lse[qq] : 0.f;
+            del_s[tid] = qq < p.Tq ? del[qq] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {                               // S^T / dP^T tile: rows = my 16 keys, cols = 16 queries
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_rows<T>(st, Kme, LDK, Qs + n * 16 * LDK, LDK, DK, lane);
+            mma_rows<T>(dpt, Vme, LDK, Os + n * 16 * LDK, LDK, DK, lane);
+            const int qc = n * 16 + r;
+            const bool qok = (i0 + qc) < p.Tq;
+            const float l = lse_s[qc], dl = del_s[qc];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = j0 + w * 16 + 4 * g + e;
+                const float pv = (qok && key < klen) ? expf(st[e] * p.scale - l) : 0.f;
+                const float ds = pv * (dpt[e] - dl) * p.scale;
+                Pme[(4 * g + e) * LDT + qc] = (T)pv;
+                Sme[(4 * g + e) * LDT + qc] = (T)ds;
+            }
+        }
+        __syncthreads();                                            // P^T / dS^T tiles visible
+#pragma unroll
+        for (int n = 0; n < DN; ++n) {
+            mma_rows<T>(dVa[n], Pme, LDT, Ot + n * 16 * LDT, LDT, 64, lane);
+            mma_rows<T>(dKa[n], Sme, LDT, Qt + n * 16 * LDT, LDT, 64, lane);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int key = j0 + w * 16 + 4 * g + e;
+        if (key < p.Tk) {
+            T* ok = p.dk + (long long)b * p.dk_bs + (long long)key * p.dk_rs + (long long)h * D;
+            T* ov = p.dv + (long long)b * p.dv_bs + (long long)key * p.dv_rs + (long long)h * D;
+#pragma unroll
+            for (int n = 0; n < DN; ++n) { ok[n * 16 + r] = (T)dKa[n][e]; ov[n * 16 + r] = (T)dVa[n][e]; }
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const BwdP p) {
+    typedef bf16_t T;
+    constexpr int DK = (D + 31) / 32 * 32, DN = D / 16;
+    constexpr int LDK = DK + 8, LDT = 64 + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Qs = (T*)smem;                 // [64][LDK]   queries of this workgroup
+    T* Os = Qs + 64 * LDK;            // [64][LDK]   dO
+    T* Ks = Os + 64 * LDK;            // [64][LDK]   current key tile
+    T* Vs = Ks + 64 * LDK;            // [64][LDK]
+    T* Kt = Vs + 64 * LDK;            // [D][LDT]    K^T (B operand of dQ)
+    T* Sw = Kt + D * LDT;             // [4][16][LDT] dS per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int i0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const bool vec = p.vec_ok != 0;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+    const T* Q = p.q + (long long)b * p.q_bs + (long long)h * D;
+    const T* K = p.k + (long long)b * p.k_bs + (long long)h * D;
+    const T* V = p.v + (long long)b * p.v_bs + (long long)h * D;
+    const T* DO = p.dout + (long long)b * p.do_bs + (long long)h * D;
+    const float* lse = p.lse + ((long long)b * p.H + h) * p.Tq;
+    const float* del = p.delta + ((long long)b * p.H + h) * p.Tq;
+
+    stage_rows<T, D, DK>(Qs, LDK, Q, p.q_rs, i0, p.Tq, vec, tid);
+    stage_rows<T, D, DK>(Os, LDK, DO, p.do_rs, i0, p.Tq, vec, tid);
+    float lrow[4], drow[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int qq = i0 + w * 16 + 4 * g + e;
+        lrow[e] = qq < p.Tq ? lse[qq] : 0.f;
+        drow[e] = qq < p.Tq ? del[qq] : 0.f;
+    }
+    f32x4 dQa[DN];
+#pragma unroll
+    for (int n = 0; n < DN; ++n) dQa[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    T* Sme = Sw + w * 16 * LDT;
+    const T* Qme = Qs + w * 16 * LDK;
+    const T* Ome = Os + w * 16 * LDK;
+
+    for (int j0 = 0; j0 < klen; j0 += 64) {
+        __syncthreads();
+        stage_rows<T, D, DK>(Ks, LDK, K, p.k_rs, j0, klen, vec, tid);
+        stage_rows<T, D, DK>(Vs, LDK, V, p.v_rs, j0, klen, vec, tid);
+        stage_vt<T, D>(Kt, LDT, K, p.k_rs, j0, klen, vec, tid);
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {                               // S / dP tile: rows = my 16 queries, cols = 16 keys
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_rows<T>(st, Qme, LDK, Ks + n * 16 * LDK, LDK, DK, lane);
+            mma_rows<T>(dpt, Ome, LDK, Vs + n * 16 * LDK, LDK, DK, lane);
+            const bool kok = (j0 + n * 16 + r) < klen;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = kok ? expf(st[e] * p.scale - lrow[e]) : 0.f;
+                Sme[(4 * g + e) * LDT + n * 16 + r] = (T)(pv * (dpt[e] - drow[e]) * p.scale);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < DN; ++n) mma_rows<T>(dQa[n], Sme, LDT, Kt + n * 16 * LDT, LDT, 64, lane);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int qq = i0 + w * 16 + 4 * g + e;
+        if (qq < p.Tq) {
+            T* o = p.dq + (long long)b * p.dq_bs + (long long)qq * p.dq_rs + (long long)h * D;
+#pragma unroll
+            for (int n = 0; n < DN; ++n) o[n * 16 + r] = (T)dQa[n][e];
+        }
+    }
+}
+
+template <int D>
+int launch_bwd(const BwdP& p, hipStream_t st) {
+    constexpr int DK = (D + 31) / 32 * 32;
+    constexpr int LDK = DK + 8, LDT = 64 + 8;
+    const int lds_kv = 2 * (4 * 64 * LDK + 2 * D * LDT + 2 * 4 * 16 * LDT) + 2 * 64 * 4;
+    const int lds_q = 2 * (4 * 64 * LDK + D * LDT + 4 * 16 * LDT);
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_bwd_q_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q) != hipSuccess) {
+            av_set_error("av_attention_bwd: cannot raise dynamic LDS (%d / %d)", lds_kv, lds_q);
+            return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<D>, dim3((p.Tk + 63) / 64, p.H, p.B), dim3(256), lds_kv, st, p);
+    AV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_q_kernel<D>, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), lds_q, st, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+}  // namespace
+
+extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int D,
+                                const long long* strides /* 16: (bs, rs) of q,k,v,o,dout,dq,dk,dv */, const int* klen, float scale,
+                                void* stream) {
+    AV_CHECK(q && k && v && o && dout && lse && delta_ws && dq && dk && dv && strides, "av_attention_bwd: null pointer");
+    AV_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0, "av_attention_bwd: bad shape");
+    BwdP p;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.dout = (const bf16_t*)dout;
+    p.lse = lse; p.delta = delta_ws; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.klen = klen;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
+    p.q_bs = strides[0]; p.q_rs = strides[1]; p.k_bs = strides[2]; p.k_rs = strides[3]; p.v_bs = strides[4]; p.v_rs = strides[5];
+    const long long o_bs = strides[6], o_rs = strides[7];
+    p.do_bs = strides[8]; p.do_rs = strides[9]; p.dq_bs = strides[10]; p.dq_rs = strides[11]; p.dk_bs = strides[12]; p.dk_rs = strides[13];
+    p.dv_bs = strides[14]; p.dv_rs = strides[15];
+    p.scale = scale;
+    auto al = [&](const void* ptr, long long bs, long long rs) {
+        return ((uintptr_t)ptr % 16 == 0) && ((bs * 2) % 16 == 0) && ((rs * 2) % 16 == 0) && ((D * 2) % 16 == 0);
+    };
+    p.vec_ok = al(q, p.q_bs, p.q_rs) && al(k, p.k_bs, p.k_rs) && al(v, p.v_bs, p.v_rs) && al(dout, p.do_bs, p.do_rs);
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)B * H * Tq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws,
+                       B, H, Tq, D, o_bs, o_rs, p.do_bs, p.do_rs);
+    AV_LAUNCH_CHECK();
+    switch (D) {
+        case 16: return launch_bwd<16>(p, st);
+        case 32: return launch_bwd<32>(p, st);
+        case 64: return launch_bwd<64>(p, st);
+        case 128: return launch_bwd<128>(p, st);
+        default: av_set_error("av_attention_bwd: head_dim %d not in {16,32,64,128}", D); return AV_ERR_ARG;
+    }
+}

@@ -142,7 +142,7 @@ class _FusionFn(torch.autograd.Function):
         q = ops.linear(a, Win[:E], bin_[:E].contiguous()).view(B, Tv, nh, hd)
         kv = ops.linear(v, Win[E:], bin_[E:].contiguous()).view(B, Tv, 2, nh, hd)
         scale = hd ** -0.5                                   # torch scales q by 1/sqrt(hd) (torch:functional.py:6578)
-        o, _ = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], None, scale, need_lse=False)
+        o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], None, scale, need_lse=save)
         a2v = ops.linear(o.view(B, Tv, E), c(mha.out_proj.weight), mha.out_proj.bias.data)
         fused = ops.linear(a2v, c(mod.fusion_proj.weight), mod.fusion_proj.bias.data)
         x_tm = torch.empty((Tv, B, E), dtype=dtype, device=dev)
@@ -150,7 +150,7 @@ class _FusionFn(torch.autograd.Function):
         out_bt, lctx = lstm_forward(mod, x_tm, save)
         out = ops.cast(out_bt, torch.float32)
         if save:
-            fctx.saved = dict(ws=ws, vis_t=vis_t, a_in_t=a_in_t, v=v, a=a, q=q, kv=kv, o=o, a2v=a2v, fused=fused, lstm=lctx,
+            fctx.saved = dict(ws=ws, vis_t=vis_t, a_in_t=a_in_t, v=v, a=a, q=q, kv=kv, o=o, lse=lse, a2v=a2v, fused=fused, lstm=lctx,
                               shape=(B, Tv, Ta, Da, Dv), dtype=dtype, groups=groups)
         else:
             fctx.saved = None
@@ -184,7 +184,7 @@ class _FusionFn(torch.autograd.Function):
         do = ops.matmul_nn(da2v, c(mha.out_proj.weight)).view(B, Tv, nh, hd)
         q, kv = s["q"], s["kv"]
         dq = torch.empty_like(q); dkv = torch.empty_like(kv)
-        ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], do, dq, dkv[:, :, 0], dkv[:, :, 1], None, hd ** -0.5)
+        ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], do, dq, dkv[:, :, 0], dkv[:, :, 1], None, hd ** -0.5, o=s["o"], lse=s["lse"])
         Win = c(mha.in_proj_weight)
         dq2, dkv2 = dq.view(M, E), dkv.view(M, 2 * E)
         dWin = torch.empty((3 * E, E), dtype=torch.float32, device=dout.device)

@@ -229,7 +229,7 @@ class Wav2Vec2ModelHIP(nn.Module):
             x1, mu1, rs1 = ops.layernorm_fwd(h, self.P(p + "layer_norm.weight").data, self.P(p + "layer_norm.bias").data,
                                              out_dtype=dtype, eps=eps, save_stats=True)
             qkv = ops.linear(x1, self.qkv_w(li, dtype), self.qkv_b(li), out_dtype=dtype).view(B, T, 3, nh, hd)
-            ao, _ = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], klen, scale, need_lse=False)
+            ao, lse = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], klen, scale, need_lse=keep_ctx)
             h2 = ops.linear(ao.view(B, T, Hd), self.c(p + "attention.out_proj.weight", dtype), self.P(p + "attention.out_proj.bias").data,
                             out_dtype=torch.float32, R=h)
             x2, mu2, rs2 = ops.layernorm_fwd(h2, self.P(p + "final_layer_norm.weight").data, self.P(p + "final_layer_norm.bias").data,
@@ -241,7 +241,7 @@ class Wav2Vec2ModelHIP(nn.Module):
                             out_dtype=torch.float32, R=h2)
             if keep_ctx:
                 tr = train[li]
-                saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, h2=h2, mu2=mu2, rs2=rs2, u=u,
+                saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, lse=lse, h2=h2, mu2=mu2, rs2=rs2, u=u,
                                  x1=x1 if tr else None, x2=x2 if tr else None, g=g if tr else None)
             h = h3
         last, muf, rsf = ops.layernorm_fwd(h, self.P("encoder.layer_norm.weight").data, self.P("encoder.layer_norm.bias").data,
@@ -303,7 +303,8 @@ class Wav2Vec2ModelHIP(nn.Module):
                 grads[p + "attention.out_proj.bias"] = ops.colsum(dh2.view(M, Hd))
             qkv = s["qkv"]
             dqkv = torch.empty_like(qkv)
-            ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dao, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx["klen"], scale)
+            ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dao, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx["klen"], scale,
+                              o=s["ao"], lse=s["lse"])
             dx1 = ops.matmul_nn(dqkv.view(M, 3 * Hd), self.qkv_w(li, dtype), out_dtype=dtype, b_is_weight=True)
             if tr:
                 dW = ops.matmul_tn(dqkv.view(M, 3 * Hd), s["x1"].view(M, Hd))

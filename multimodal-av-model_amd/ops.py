@@ -281,7 +281,7 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, klen: Optional[Tensor], scale
 
 
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: Tensor, dv: Tensor, klen: Optional[Tensor],
-                  scale: float) -> None:
+                  scale: float, o: Optional[Tensor] = None, lse: Optional[Tensor] = None) -> None:
     """Backward of attention_fwd from batched MFMA GEMMs + row kernels (P is re-materialised, T x T is small here):
     P = softmax(scale QK^T); dV = P^T dO; dP = dO V^T; dS = scale P o (dP - rowsum(dP o P)); dQ = dS K; dK = dS^T Q.
     dq/dk/dv are [B,T,H,D] output views (written in place)."""
@@ -289,6 +289,13 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: T
         _chk_view(t, n)
     B, Tq, H, D = q.shape
     Tk = k.shape[1]
+    if q.dtype == torch.bfloat16 and o is not None and lse is not None:     # fused flash-style backward (attention_bwd.hip)
+        _chk_view(o, "o")
+        st = (C.c_longlong * 16)(*[x for t in (q, k, v, o, do, dq, dk, dv) for x in (t.stride(0), t.stride(1))])
+        delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
+        L.check(L.lib().av_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                         B, H, Tq, Tk, D, st, ptr(klen), scale, stream()), "av_attention_bwd")
+        return
     ld = (Tk + 7) // 8 * 8
     dev = q.device
     S = torch.empty((B, H, Tq, ld), dtype=torch.float32, device=dev)

@@ -54,7 +54,8 @@ def test_audio_backward_vs_oracle(precision, tol):
         if p.requires_grad:
             ref = osd[n].grad
             if "k_proj.bias" in n:      # mathematically zero gradient
-                assert float(p.grad.abs().max()) < 1e-2 * max(1.0, float(wl.abs().max()))
+                # only rounding noise may remain: sum over keys of bf16-rounded dK (fp32 mode: ~1e-6)
+                assert float(p.grad.abs().max()) < (1e-4 if precision == "fp32" else 5e-2) * max(1.0, float(wl.abs().max()))
                 continue
             rel = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12))
             worst = max(worst, rel)

@@ -209,6 +209,11 @@ def test_attention_fwd_bwd(dtype, B, H, Tq, Tk, D, masked):
     dq = torch.empty(B, Tq, H, D, device="cuda", dtype=dtype); dk = torch.empty(B, Tk, H, D, device="cuda", dtype=dtype)
     dv = torch.empty(B, Tk, H, D, device="cuda", dtype=dtype)
     ops.attention_bwd(q, k, v, do, dq, dk, dv, klen, scale)
+    if dtype == torch.bfloat16:      # fused flash-style backward must agree as well
+        dq2, dk2, dv2 = torch.empty_like(dq), torch.empty_like(dk), torch.empty_like(dv)
+        ops.attention_bwd(q, k, v, do, dq2, dk2, dv2, klen, scale, o=o, lse=lse)
+        for a_, b_, r_ in ((dq2, dq, qr.grad), (dk2, dk, kr.grad), (dv2, dv, vr.grad)):
+            torch.testing.assert_close(a_.float().permute(0, 2, 1, 3), r_, rtol=5e-2, atol=5e-2)
     btol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
     torch.testing.assert_close(dq.float().permute(0, 2, 1, 3), qr.grad, **btol)
     torch.testing.assert_close(dk.float().permute(0, 2, 1, 3), kr.grad, **btol)
