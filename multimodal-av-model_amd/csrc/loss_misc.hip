@@ -88,6 +88,32 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// multi-tensor Adam: one launch for every trainable tensor.  ptrs[t] = {param, grad, exp_avg, exp_avg_sq}; chunk c covers
+// elements [chunk_start[c], +chunk_elems) of tensor chunk_tensor[c].
+__global__ __launch_bounds__(256) void adam_multi_kernel(const unsigned long long* __restrict__ ptrs, const long long* __restrict__ sizes,
+                                                         const float* __restrict__ lrs, const int* __restrict__ chunk_tensor,
+                                                         const long long* __restrict__ chunk_start, int chunk_elems, float b1, float b2,
+                                                         float eps, float bc1, float bc2_sqrt, float gscale) {
+    const int c = blockIdx.x;
+    const int t = chunk_tensor[c];
+    float* p = (float*)ptrs[4 * t + 0];
+    const float* g = (const float*)ptrs[4 * t + 1];
+    float* m = (float*)ptrs[4 * t + 2];
+    float* v = (float*)ptrs[4 * t + 3];
+    const long long n = sizes[t];
+    const long long s0 = chunk_start[c];
+    long long s1 = s0 + chunk_elems;
+    if (s1 > n) s1 = n;
+    const float step_size = lrs[t] / bc1;
+    for (long long i = s0 + threadIdx.x; i < s1; i += 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
 inline int ew_grid(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -136,6 +162,18 @@ extern "C" int av_adam_step(float* p, const float* g, float* m, float* v, long l
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_adam_multi(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
+                             int n_chunks, int chunk_elems, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    AV_CHECK(ptrs && sizes && lrs && chunk_tensor && chunk_start && n_chunks >= 0 && chunk_elems > 0 && step >= 1, "av_adam_multi: bad args");
+    if (n_chunks == 0) return AV_OK;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)ptrs, sizes, lrs,
+                       chunk_tensor, chunk_start, chunk_elems, beta1, beta2, eps, bc1, bc2s, grad_scale);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

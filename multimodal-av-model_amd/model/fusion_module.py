@@ -237,8 +237,10 @@ class CrossAttentionFusion(nn.Module):
             raise ValueError("CrossAttentionFusion: mask is required (the reference dereferences it unconditionally, :66)")
         if not audio_feat.is_cuda:
             raise RuntimeError("CrossAttentionFusion (HIP): inputs must be on the GPU; there is no CPU fallback")
-        names = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("cross_attn_visual.")]
-        params = [dict(self.named_parameters())[n] for n in names]
+        if getattr(self, "_np", None) is None:
+            self._np = [(n, p) for n, p in self.named_parameters() if not n.startswith("cross_attn_visual.")]
+        names = [n for n, p in self._np if p.requires_grad]
+        params = [p for n, p in self._np if p.requires_grad]
         save = torch.is_grad_enabled() and (bool(names) or audio_feat.requires_grad or visual_feat.requires_grad)
         out, lens, m_out = _FusionFn.apply(self, save, names, groups, visual_feat, audio_feat, mask, *params)
         self.last_mask = m_out

@@ -106,10 +106,14 @@ class Wav2Vec2ModelHIP(nn.Module):
 
     # ---- parameter access ------------------------------------------------------------------------------------
     def P(self, name: str) -> Tensor:
-        m = self
-        for p in name.split("."):
-            m = m._modules[p] if p in m._modules else m._parameters[p]
-        return m
+        pc = self.__dict__.setdefault("_pcache", {})
+        hit = pc.get(name)
+        if hit is None:
+            m = self
+            for p in name.split("."):
+                m = m._modules[p] if p in m._modules else m._parameters[p]
+            pc[name] = hit = m
+        return hit
 
     def c(self, name: str, dtype) -> Tensor:
         """Parameter in the compute dtype (cached)."""
@@ -147,8 +151,10 @@ class Wav2Vec2ModelHIP(nn.Module):
 
     # ---- which layers need a backward -----------------------------------------------------------------------
     def trainable_layers(self) -> List[bool]:
-        return [any(p.requires_grad for p in self._modules["encoder"]._modules["layers"]._modules[str(li)].parameters())
-                for li in range(self.cfg["num_hidden_layers"])]
+        if getattr(self, "_layer_params", None) is None:
+            self._layer_params = [list(self._modules["encoder"]._modules["layers"]._modules[str(li)].parameters())
+                                  for li in range(self.cfg["num_hidden_layers"])]
+        return [any(p.requires_grad for p in ps) for ps in self._layer_params]
 
     def check_freeze_policy(self):
         bad = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("encoder.layers.")]
@@ -347,10 +353,15 @@ class _EncodeFn(torch.autograd.Function):
 
 
 def w2v2_apply(model: Wav2Vec2ModelHIP, wav: Tensor, attention_mask: Optional[Tensor]):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
-        model.check_freeze_policy()
-        names = [n for n, p in model.named_parameters() if p.requires_grad]
-        params = [model.P(n) for n in names]
+    if getattr(model, "_np", None) is None:
+        model._np = list(model.named_parameters())
+    flags = tuple(p.requires_grad for _, p in model._np)
+    if torch.is_grad_enabled() and any(flags):
+        if getattr(model, "_np_flags", None) != flags:          # the freeze policy changed: re-validate, rebuild the lists
+            model.check_freeze_policy()
+            model._np_flags = flags
+            model._np_train = ([n for (n, p), f in zip(model._np, flags) if f], [p for (n, p), f in zip(model._np, flags) if f])
+        names, params = model._np_train
         return _EncodeFn.apply(model, wav, attention_mask, names, *params)
     with torch.no_grad():
         last, mid, _ = model.encode(wav, attention_mask, save=False)

@@ -15,13 +15,29 @@ class AvAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = 1.0
 
+    CHUNK = 65536
+
+    def _plan(self, plist):
+        """Static part of the multi-tensor launch: sizes, learning rates, chunk table (cached per parameter set)."""
+        key = tuple((p.data_ptr(), p.numel(), lr) for p, lr, _ in plist)
+        if getattr(self, "_plan_key", None) != key:
+            dev = plist[0][0].device
+            sizes = torch.tensor([p.numel() for p, _, _ in plist], dtype=torch.long, device=dev)
+            lrs = torch.tensor([lr for _, lr, _ in plist], dtype=torch.float32, device=dev)
+            ct, cs = [], []
+            for t, (p, _, _) in enumerate(plist):
+                for s0 in range(0, p.numel(), self.CHUNK):
+                    ct.append(t); cs.append(s0)
+            self._plan_key = key
+            self._plan_data = (sizes, lrs, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(cs, dtype=torch.long, device=dev), len(ct))
+        return self._plan_data
+
     @torch.no_grad()
     def step(self, closure=None):
+        """One fused multi-tensor launch for all parameters that have a gradient (same step count, per-group lr)."""
         loss = closure() if closure is not None else None
-        st = ops.stream()
-        fn = L.lib().av_adam_step
+        plist = []
         for group in self.param_groups:
-            b1, b2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -33,8 +49,37 @@ class AvAdam(torch.optim.Optimizer):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] = int(state["step"]) + 1
+                plist.append((p, float(group["lr"]), state))
+        if not plist:
+            return loss
+        steps = {st["step"] for _, _, st in plist}
+        b1, b2 = self.param_groups[0]["betas"]
+        eps = float(self.param_groups[0]["eps"])
+        if len(steps) != 1 or any(g["betas"] != (b1, b2) or g["eps"] != eps for g in self.param_groups):
+            return self._step_per_tensor(plist, loss)
+        sizes, lrs, ct, cs, nch = self._plan(plist)
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p, _, _ in plist]
+        flat = []
+        for (p, _, st), g in zip(plist, grads):
+            flat += [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()]
+        ptrs = torch.tensor(flat, dtype=torch.long).to(plist[0][0].device, non_blocking=True)
+        L.check(L.lib().av_adam_multi(ops.ptr(ptrs), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK, float(b1),
+                                      float(b2), eps, steps.pop(), float(self.grad_scale), ops.stream()), "av_adam_multi")
+        self._keep = (ptrs, grads)                              # alive until the next step (stream-ordered use)
+        torch.autograd.graph.increment_version([p for p, _, _ in plist])     # refresh compute-dtype weight caches
+        return loss
+
+    def _step_per_tensor(self, plist, loss):
+        st_ = ops.stream()
+        fn = L.lib().av_adam_step
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 L.check(fn(ops.ptr(p), ops.ptr(g), ops.ptr(state["exp_avg"]), ops.ptr(state["exp_avg_sq"]), p.numel(), float(group["lr"]),
-                           float(b1), float(b2), float(group["eps"]), state["step"], float(self.grad_scale), st), "av_adam_step")
-                torch.autograd.graph.increment_version(p)   # updated in place by the kernel: refresh compute-dtype caches
+                           float(b1), float(b2), float(group["eps"]), state["step"], float(self.grad_scale), st_), "av_adam_step")
+                torch.autograd.graph.increment_version(p)
         return loss

@@ -184,3 +184,23 @@ def test_fusion_groups_equals_separate_calls():
     with torch.no_grad():
         bad, _ = mod(torch.cat([vis1, vis2]), torch.cat([aud, aud]), torch.cat([m1, m2]), groups=1)
     assert float((bad[B:] - o2).abs().max()) > 1e-3      # without groups the second speaker would be resampled differently
+
+
+def test_avadam_multi_tensor_matches_torch():
+    optim = pkg("optim")
+    g = torch.Generator().manual_seed(12)
+    shapes = [(1000, 33), (70000,), (5,), (128, 1024)]
+    ref = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    mine = [r.detach().clone().cuda().requires_grad_(True) for r in ref]
+    o_ref = torch.optim.Adam([{"params": ref[:2], "lr": 1e-4}, {"params": ref[2:], "lr": 2e-5}])
+    o_mine = optim.AvAdam([{"params": mine[:2], "lr": 1e-4}, {"params": mine[2:], "lr": 2e-5}])
+    for step in range(3):
+        for r, m in zip(ref, mine):
+            gr = torch.randn(r.shape, generator=g)
+            r.grad = gr.clone(); m.grad = gr.cuda()
+        if step == 1:
+            ref[2].grad = None; mine[2].grad = None          # a parameter without a gradient is skipped
+        o_ref.step(); o_mine.step()
+    for r, m in zip(ref, mine):
+        torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-6, atol=1e-7)
+    assert set(o_mine.state[mine[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
