@@ -24,18 +24,29 @@ struct BwdP {
     int vec_ok;
 };
 
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, int B, int H,
+// delta[b][h][t] = sum_d dO o O.  One wavefront per (b, t): the H*D contiguous elements are read with 16-B loads, each lane
+// reduces its 8-element chunks and the lanes of one head are combined with shuffles (chunks per head = D/8, power of 2).
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, int B, int H,
                                   int T, int D, long long o_bs, long long o_rs, long long do_bs, long long do_rs) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // (b, h, t)
-    if (i >= (long long)B * H * T) return;
-    const int t = (int)(i % T);
-    const int h = (int)((i / T) % H);
-    const int b = (int)(i / ((long long)T * H));
-    const bf16_t* po = o + (long long)b * o_bs + (long long)t * o_rs + (long long)h * D;
-    const bf16_t* pd = dout + (long long)b * do_bs + (long long)t * do_rs + (long long)h * D;
-    float s = 0.f;
-    for (int d = 0; d < D; ++d) s += (float)po[d] * (float)pd[d];
-    delta[i] = s;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (b, t)
+    if (row >= (long long)B * T) return;
+    const int t = (int)(row % T), b = (int)(row / T);
+    const bf16_t* po = o + (long long)b * o_bs + (long long)t * o_rs;
+    const bf16_t* pd = dout + (long long)b * do_bs + (long long)t * do_rs;
+    const int cph = D / 8;                                                         // 16-B chunks per head
+    const int nchunk = H * cph;
+    for (int c0 = 0; c0 < nchunk; c0 += 64) {
+        const int c = c0 + lane;
+        float s = 0.f;
+        if (c < nchunk) {
+            const bf16x8 a = *(const bf16x8*)(po + c * 8), d = *(const bf16x8*)(pd + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)d[e];
+        }
+        for (int off = 1; off < cph && off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+        if (c < nchunk && (c % cph) == 0) delta[((long long)b * H + c / cph) * T + t] = s;
+    }
 }
 
 template <int D>
@@ -249,8 +260,12 @@ extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, con
     p.vec_ok = al(q, p.q_bs, p.q_rs) && al(k, p.k_bs, p.k_rs) && al(v, p.v_bs, p.v_rs) && al(dout, p.do_bs, p.do_rs);
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)B * H * Tq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws,
-                       B, H, Tq, D, o_bs, o_rs, p.do_bs, p.do_rs);
+    AV_CHECK(D % 8 == 0 && ((D / 8) & (D / 8 - 1)) == 0 && (D / 8 <= 64) && (uintptr_t)o % 16 == 0 && (uintptr_t)dout % 16 == 0 &&
+             (o_bs * 2) % 16 == 0 && (o_rs * 2) % 16 == 0 && (p.do_bs * 2) % 16 == 0 && (p.do_rs * 2) % 16 == 0,
+             "av_attention_bwd: o / dout must be 16-byte aligned views and D/8 a power of two");
+    (void)n;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long long)B * Tq + 3) / 4)), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout,
+                       delta_ws, B, H, Tq, D, o_bs, o_rs, p.do_bs, p.do_rs);
     AV_LAUNCH_CHECK();
     switch (D) {
         case 16: return launch_bwd<16>(p, st);

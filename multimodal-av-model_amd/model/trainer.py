@@ -16,6 +16,7 @@ from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from .. import _lib as L
@@ -155,8 +156,19 @@ class MultimodalTrainer:
             f2, il2 = self.fusion_module(vf2, a2, mask=m2)
             lp1 = self.decoder1(f1)
             lp2 = self.decoder1(f2)
-        l1 = self.ctc_loss(lp1.transpose(0, 1), d["text1"], il1, d["text1_lengths"])
-        l2 = self.ctc_loss(lp2.transpose(0, 1), d["text2"], il2, d["text2_lengths"])
+        if self.pair_batched:
+            # one nn.functional.ctc_loss call (PyTorch-ROCm, as north_star prescribes) over the 2B items; 'mean' reduction
+            # of nn.CTCLoss = mean_i(nll_i / clamp(target_len_i, 1)) is re-applied per speaker half
+            t1, t2 = d["text1"], d["text2"]
+            Lm = max(t1.shape[1], t2.shape[1])
+            tg = torch.cat([F.pad(t1, (0, Lm - t1.shape[1])), F.pad(t2, (0, Lm - t2.shape[1]))], 0)
+            tl = torch.cat([d["text1_lengths"], d["text2_lengths"]], 0)
+            nll = F.ctc_loss(lp12.transpose(0, 1), tg, il12, tl, blank=self.tokenizer.blank_id, reduction="none", zero_infinity=True)
+            per = nll / tl.clamp_min(1).to(nll.dtype)
+            l1, l2 = per[:B].mean(), per[B:].mean()
+        else:
+            l1 = self.ctc_loss(lp1.transpose(0, 1), d["text1"], il1, d["text1_lengths"])
+            l2 = self.ctc_loss(lp2.transpose(0, 1), d["text2"], il2, d["text2_lengths"])
         total = (l1 + l2) / 2 + self.lambda_ * (c1 + c2) / 2
         out.update(visual_feat1=vf1, visual_feat2=vf2, audio_last=a1, audio_mid=mid1, fused1=f1, fused2=f2, input_lengths1=il1,
                    input_lengths2=il2, log_probs1=lp1, log_probs2=lp2, loss1=l1, loss2=l2, contrast1=c1, contrast2=c2, total=total)
