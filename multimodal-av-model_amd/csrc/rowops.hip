@@ -112,6 +112,130 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     }
 }
 
+
+// ---- vector forms for cols % 256 == 0 (the 512 / 1024-wide rows of wav2vec2): lane owns 4 consecutive elements per
+// 256-column slab -> 16-B fp32 / 8-B bf16 accesses ------------------------------------------------------------------
+__device__ __forceinline__ f32x4 ld4(const void* p, long long i, int dtype) {
+    if (dtype == AV_F32) return *(const f32x4*)((const float*)p + i);
+    const bf16x4 v = *(const bf16x4*)((const bf16_t*)p + i);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4(void* p, long long i, int dtype, const f32x4& v) {
+    if (dtype == AV_F32) *(f32x4*)((float*)p + i) = v;
+    else {
+        bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+        *(bf16x4*)((bf16_t*)p + i) = o;
+    }
+}
+
+template <int ACT, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const void* __restrict__ x, int xdt, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, void* __restrict__ y, int ydt,
+                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o, long long rows, float eps) {
+    constexpr int cols = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long base = row * cols;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) { v[it] = ld4(x, base + it * 256 + lane * 4, xdt); s += v[it][0] + v[it][1] + v[it][2] + v[it][3]; }
+    const float mean = wave_sum(s) / cols;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NV; ++it)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[it][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int c = it * 256 + lane * 4;
+        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = (v[it][e] - mean) * rstd * g[e] + b[e];
+            if (ACT == AV_ACT_GELU) t = gelu_f(t);
+            o[e] = t;
+        }
+        st4(y, base + c, ydt, o);
+    }
+    if (lane == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (rstd_o) rstd_o[row] = rstd;
+    }
+}
+
+template <int NV, bool PG>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict__ x, int xdt, const void* __restrict__ dy, int dydt,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                         float* __restrict__ dx, float* __restrict__ dgb, long long rows,
+                                                         long long rows_per_block) {
+    constexpr int cols = NV * 256;
+    __shared__ float red[4][2][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    long long r_end = r_begin + rows_per_block;
+    if (r_end > rows) r_end = rows;
+    f32x4 gam[NV];
+#pragma unroll
+    for (int it = 0; it < NV; ++it) gam[it] = *(const f32x4*)(gamma + it * 256 + lane * 4);
+    f32x4 dg[PG ? NV : 1], db[PG ? NV : 1];
+#pragma unroll
+    for (int it = 0; it < (PG ? NV : 1); ++it) { dg[it] = f32x4{0.f, 0.f, 0.f, 0.f}; db[it] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (long long row = r_begin + w; row < r_end; row += 4) {
+        const long long base = row * cols;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const f32x4 d = ld4(dy, base + it * 256 + lane * 4, dydt);
+            const f32x4 xv = ld4(x, base + it * 256 + lane * 4, xdt);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[it][e] = (xv[e] - mu) * rs;
+                g[it][e] = d[e] * gam[it][e];
+                if (PG) { dg[it][e] += d[e] * xh[it][e]; db[it][e] += d[e]; }
+                s1 += g[it][e];
+                s2 += g[it][e] * xh[it][e];
+            }
+        }
+        s1 = wave_sum(s1) / cols;
+        s2 = wave_sum(s2) / cols;
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const long long off = base + it * 256 + lane * 4;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - s1 - xh[it][e] * s2);
+            if (dres) {
+                const f32x4 rr = *(const f32x4*)(dres + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += rr[e];
+            }
+            *(f32x4*)(dx + off) = o;
+        }
+    }
+    if (PG && dgb) {
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[w][0][lane * 4 + e] = dg[PG ? it : 0][e]; red[w][1][lane * 4 + e] = db[PG ? it : 0][e]; }
+            __syncthreads();
+            {
+                const int c = threadIdx.x;       // 256 threads <-> the 256 columns of this slab
+                float* o = dgb + (long long)blockIdx.x * 2 * cols;
+                o[it * 256 + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+                o[cols + it * 256 + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lsm_fwd_kernel(const void* __restrict__ x, int xdt, float* __restrict__ y, long long rows, int cols) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -219,6 +343,18 @@ extern "C" int av_layernorm_fwd(const void* x, int xdt, const float* gamma, cons
     AV_CHECK(act == AV_ACT_NONE || act == AV_ACT_GELU, "av_layernorm_fwd: bad act %d", act);
     if (rows == 0) return AV_OK;
     dim3 grid((unsigned)((rows + 3) / 4));
+    const bool xa = xdt == AV_F32 ? ((uintptr_t)x % 16 == 0) : ((uintptr_t)x % 8 == 0);
+    const bool ya = ydt == AV_F32 ? ((uintptr_t)y % 16 == 0) : ((uintptr_t)y % 8 == 0);
+    if (cols % 256 == 0 && cols <= 2048 && xa && ya && (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0) {
+#define LNV(A, N) hipLaunchKernelGGL((ln_fwd_vec_kernel<A, N>), grid, dim3(256), 0, (hipStream_t)stream, x, xdt, gamma, beta, y, ydt, mean, rstd, rows, eps)
+#define LNV_N(A) do { switch (cols / 256) { case 1: LNV(A, 1); break; case 2: LNV(A, 2); break; case 3: LNV(A, 3); break; case 4: LNV(A, 4); break; \
+                                           case 5: LNV(A, 5); break; case 6: LNV(A, 6); break; case 7: LNV(A, 7); break; default: LNV(A, 8); } } while (0)
+        if (act == AV_ACT_GELU) LNV_N(AV_ACT_GELU); else LNV_N(AV_ACT_NONE);
+#undef LNV_N
+#undef LNV
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
 #define LN_FWD(A, N) hipLaunchKernelGGL((ln_fwd_kernel<A, N>), grid, dim3(256), 0, (hipStream_t)stream, x, xdt, gamma, beta, y, ydt, mean, rstd, rows, cols, eps)
 #define LN_FWD_N(A) do { if (cols <= 64) LN_FWD(A, 1); else if (cols <= 128) LN_FWD(A, 2); else if (cols <= 512) LN_FWD(A, 8); \
                          else if (cols <= 1024) LN_FWD(A, 16); else LN_FWD(A, 32); } while (0)
@@ -238,6 +374,20 @@ extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt
     if (rows == 0) return AV_OK;
     if (!dgb_partial) nblk = (int)((rows + 3) / 4 > 65535 * 16 ? 65535 * 16 : (rows + 3) / 4);   // no partials: one row per wave
     const long long rpb = (rows + nblk - 1) / nblk;
+    {
+        const bool xa = xdt == AV_F32 ? ((uintptr_t)x % 16 == 0) : ((uintptr_t)x % 8 == 0);
+        const bool da = dydt == AV_F32 ? ((uintptr_t)dy % 16 == 0) : ((uintptr_t)dy % 8 == 0);
+        if ((cols == 256 || cols == 512 || cols == 1024 || cols == 2048) && xa && da && (uintptr_t)gamma % 16 == 0 && (uintptr_t)dx % 16 == 0 &&
+            (!dres || (uintptr_t)dres % 16 == 0)) {
+#define LBV(N, P) hipLaunchKernelGGL((ln_bwd_vec_kernel<N, P>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx, dgb_partial, rows, rpb)
+#define LBV_N(P) do { if (cols == 256) LBV(1, P); else if (cols == 512) LBV(2, P); else if (cols == 1024) LBV(4, P); else LBV(8, P); } while (0)
+            if (dgb_partial) LBV_N(true); else LBV_N(false);
+#undef LBV_N
+#undef LBV
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
+    }
 #define LN_BWD(N, P) hipLaunchKernelGGL((ln_bwd_kernel<N, P>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx, dgb_partial, rows, cols, rpb)
 #define LN_BWD_N(P) do { if (cols <= 64) LN_BWD(1, P); else if (cols <= 128) LN_BWD(2, P); else if (cols <= 512) LN_BWD(8, P); \
                          else if (cols <= 1024) LN_BWD(16, P); else LN_BWD(32, P); } while (0)
