@@ -181,12 +181,21 @@ def main():
         peak = 2500.0 if args.precision == "bf16" else 157.3
         roof = None
         if probe and probe["records"]:
-            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in probe["records"])
-            tot_fl = sum(f for _, _, f in probe["records"])
+            tot_ms = sum(r[0].elapsed_time(r[1]) for r in probe["records"])
+            tot_fl = sum(r[2] for r in probe["records"])
+            tot_by = sum(r[3] for r in probe["records"])
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")       # separate rocprofv3 --pmc passes (see file)
+            if args.precision == "bf16" and os.path.exists(pmc):
+                for kname, kv in json.load(open(pmc))["kernels"].items():
+                    if kname.startswith("void gemm_nt_bf16_kernel<128, false>"):
+                        traffic = kv["fetch_bytes_per_launch"] + kv["write_bytes_per_launch"]
             n = len(probe["records"])
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_kernel<128,false>" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>") + " (all nn.Linear-form products: forward, dX, dW, strided conv1d)",
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_note": "HBM-side bytes per launch from profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
+                    "algorithmic_bytes_per_launch": round(tot_by / n),
                     "launches_per_step": n // probe["steps"], "measured": "same workload, extra steps after the timed region, single stream", "avg_launch_us": round(1000.0 * tot_ms / n, 2),
                     "algorithmic_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
         res = {"metric": "utterances/sec (4 s clip, 25 fps 96x96 lip), full training step", "value": round(utt_s, 3),

@@ -101,7 +101,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
         const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, slot = bid >> 3;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
     }
-    const int mb = bid / nbN, nb = bid - mb * nbN;
+    // grouped ordering inside the XCD's contiguous id range: 8 row panels x all column panels, column-panel major,
+    // so that the 8 A panels AND each B panel are re-read from this XCD's L2 instead of HBM / Infinity Cache
+    constexpr int GM = 8;
+    const int per_group = GM * nbN;
+    const int grp = bid / per_group, in_grp = bid - grp * per_group;
+    const int first_m = grp * GM;
+    const int gsz = nbM - first_m < GM ? nbM - first_m : GM;
+    const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
     const int m0 = mb * BM, n0 = nb * BNT;
     const int z = blockIdx.z;
     const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;

@@ -92,7 +92,10 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
         e0.record()
         L.check(L.lib().av_gemm(C.byref(a), stream()), "av_gemm")
         e1.record()
-        pr["records"].append((e0, e1, 2.0 * M * N * K * batch))
+        es, oes = A.element_size(), C_.element_size()
+        nbytes = batch * ((M * K + N * K) * es + M * N * (oes + (4 if R is not None else 0) + (aux.element_size() if aux is not None else 0)
+                                                          + (oes if C2 is not None else 0)))
+        pr["records"].append((e0, e1, 2.0 * M * N * K * batch, float(nbytes)))
         return C_
     L.check(L.lib().av_gemm(C.byref(a), stream()), "av_gemm")
     return C_
