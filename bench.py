@@ -78,7 +78,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[1]: 32)")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--audio-passes", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--audio-passes", type=int, default=None, choices=[1, 2], help="default: 1 (deterministic mode), 2 with --regularize")
+    ap.add_argument("--regularize", action="store_true", help="HF-default dropout 0.1 / LayerDrop 0.1 / SpecAugment 0.05 and two audio passes")
     ap.add_argument("--lambda", dest="lambda_", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
@@ -110,7 +111,12 @@ def main():
     dm = imp("model.decoder"); tr = imp("model.trainer"); tok = imp("utils.tokenizer"); dp = imp("parallel.dp"); ops = imp("ops")
     L = imp("_lib")
     imp("precision").set_precision(args.precision)
-    cfg = init.W2V2_LARGE
+    cfg = dict(init.W2V2_LARGE)
+    if args.regularize:
+        cfg.update(hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, feat_proj_dropout=0.0, layerdrop=0.1,
+                   mask_time_prob=0.05, mask_time_length=10, mask_time_min_masks=2)
+    if args.audio_passes is None:
+        args.audio_passes = 2 if args.regularize else 1
 
     ve = enc.VisualEncoder(); ve.load_state_dict(init.visual_state_dict())
     for p in ve.parameters():
@@ -204,7 +210,7 @@ def main():
                "config": {"workload": f"configs[1]: batch {args.batch}/GPU x {args.seconds:g} s (T_audio {T_audio}, T_enc {T_enc}, "
                                       f"{T_v} lip frames 96x96 x 2 speakers), wav2vec2-large + ResNet-18 + fusion BiLSTM + CTC, "
                                       "fwd+bwd+Adam, random-init weights",
-                          "global_batch": args.batch * world, "parallelism": f"dp{world}", "audio_passes": args.audio_passes,
+                          "global_batch": args.batch * world, "parallelism": f"dp{world}", "audio_passes": args.audio_passes, "wav2vec2_regularizers": "hf-defaults" if args.regularize else "off (deterministic)",
                           "lambda_contrastive": args.lambda_, "final_loss": round(loss, 4),
                           "algorithmic_gflop_per_utt": round(fl / 1e9, 1),
                           "step_tflops": round(fl * utt_s / 1e12, 1), "step_frac_of_mfma_peak": round(fl * utt_s / 1e12 / peak, 4)},

@@ -45,7 +45,7 @@ int av_version(void);
  * conv (hf:360-368), nn.Conv2d of the ResNet trunk (model/encoder.py:9-12,36), nn.Conv3d front-end
  * (model/encoder.py:61), and all the dX / dW products of their backward passes.
  * epilogue, in order: v = alpha*acc; v += bias[n]; C2[m][n] = v (optional pre-activation copy);
- * act; v += R[m][n] (fp32 residual, may alias C); C[m][n] = v;  optional per-column sum / sum-of-squares
+ * act; optional dropout; v += R[m][n] (fp32 residual, may alias C); C[m][n] = v;  optional per-column sum / sum-of-squares
  * partials for train-mode BatchNorm statistics (model/trainer.py:54): stats[blockRow][0/1][n].               */
 typedef struct av_gemm_args {
     const void* A;
@@ -67,6 +67,12 @@ typedef struct av_gemm_args {
     /* optional two-level batch: z = zo*batch_inner + zi; offsets zo*o? + zi*s? (batch_inner = 0: one level) */
     int batch_inner;
     long long oA, oB, oC;
+    /* optional dropout in the epilogue (hf:628-633,565-572 hidden / activation dropout): after the activation and BEFORE the
+     * residual, v *= mask(seed, stream, m*ldc + n) in {0, 1/(1-p)}; with AV_ACT_MUL_GELU_GRAD the same mask multiplies the
+     * gradient.  drop_p = 0 disables it. */
+    float drop_p;
+    unsigned int drop_stream;
+    unsigned long long drop_seed;
 } av_gemm_args;
 int av_gemm(const av_gemm_args* args, void* stream);
 /* out[C][Rpad] = in[R][C]^T (zero-filled for r >= R): brings dX / dW products to the fast K-contiguous form */
@@ -90,6 +96,13 @@ int av_colsum(const void* x, int xdt, float* out, long long rows, int cols, long
               void* stream);
 /* elementwise */
 int av_cast(const void* x, int xdt, void* y, int ydt, long long n, void* stream);
+/* y = cast(x * dropout_mask(seed, stream, i)) — forward dropout and its backward (same mask) in one kernel; p = 0: plain cast */
+int av_cast_dropout(const void* x, int xdt, void* y, int ydt, long long n, float p, unsigned long long seed, unsigned int stream_id,
+                    void* stream);
+/* debug / test: u[i] = the uniform number behind the mask of element i */
+int av_dropout_uniform(float* u, long long n, unsigned long long seed, unsigned int stream_id, void* stream);
+/* SpecAugment time masking (hf:1272-1296): x[row][:] = embed[:] where mask[row] != 0 */
+int av_overwrite_rows(void* x, int xdt, const unsigned char* mask, const float* embed, long long rows, int cols, void* stream);
 int av_axpby(float a, const void* x, int xdt, float b, float* y, long long n, void* stream); /* y = a*x + b*y */
 int av_mask_rows(void* x, int xdt, const unsigned char* keep, long long rows, int cols, void* stream); /* hf:752-755 */
 int av_mul_scalar_dev(const float* x, const float* scalar, float* y, long long n, void* stream); /* y = scalar[0]*x, scalar on device */
@@ -101,13 +114,15 @@ int av_mul_scalar_dev(const float* x, const float* scalar, float* y, long long n
  * keys (NULL: all Tk).  lse [B][H][Tq] fp32 (optional).  D in {16,32,64,128}. */
 int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H, int Tq,
                      int Tk, int D, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
-                     long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, void* stream);
+                     long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, float drop_p,
+                     unsigned long long drop_seed, unsigned int drop_stream, void* stream);
 /* fused (flash-style) attention backward, bf16: recomputes P from Q, K and the forward's LSE; dq/dk/dv written in place.
  * strides[16] = (batch stride, row stride) of q, k, v, o, dout, dq, dk, dv (elements; head stride = D);
  * delta_ws: B*H*Tq floats of workspace.  Backward of hf:438-463 / fusion_module.py:61. */
 int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                      float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int D,
-                     const long long* strides, const int* klen, float scale, void* stream);
+                     const long long* strides, const int* klen, float scale, float drop_p, unsigned long long drop_seed,
+                     unsigned int drop_stream, void* stream);
 /* rows of the (unfused, fp32 parity mode) attention backward: P = softmax(scale*S) with key mask; dS = scale * P o (dP - sum(dP o P)) */
 int av_softmax_rows(const float* s, void* p, int pdt, long long rows, int cols, float scale, const int* klen,
                     int rows_per_batch, int ld, void* stream);

@@ -30,6 +30,7 @@ class GemmArgs(C.Structure):
         ("cKt", i32), ("cKh", i32), ("cKw", i32), ("cSh", i32), ("cSw", i32), ("cPt", i32), ("cPh", i32), ("cPw", i32),
         ("cOh", i32), ("cOw", i32),
         ("batch_inner", i32), ("oA", ll), ("oB", ll), ("oC", ll),
+        ("drop_p", f32), ("drop_stream", C.c_uint), ("drop_seed", C.c_ulonglong),
     ]
 
 
@@ -45,11 +46,14 @@ SIGNATURES = {
     "av_log_softmax_bwd": [vp, vp, vp, i32, ll, i32, vp],
     "av_colsum": [vp, i32, vp, ll, i32, ll, i32, vp],
     "av_cast": [vp, i32, vp, i32, ll, vp],
+    "av_cast_dropout": [vp, i32, vp, i32, ll, f32, C.c_ulonglong, C.c_uint, vp],
+    "av_dropout_uniform": [vp, ll, C.c_ulonglong, C.c_uint, vp],
+    "av_overwrite_rows": [vp, i32, vp, vp, ll, i32, vp],
     "av_axpby": [f32, vp, i32, f32, vp, ll, vp],
     "av_mask_rows": [vp, i32, vp, ll, i32, vp],
     "av_mul_scalar_dev": [vp, vp, vp, ll, vp],
-    "av_attention_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ll, ll, ll, ll, ll, ll, ll, ll, vp, f32, vp],
-    "av_attention_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp],
+    "av_attention_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ll, ll, ll, ll, ll, ll, ll, ll, vp, f32, f32, C.c_ulonglong, C.c_uint, vp],
+    "av_attention_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, C.c_ulonglong, C.c_uint, vp],
     "av_softmax_rows": [vp, vp, i32, ll, i32, f32, vp, i32, i32, vp],
     "av_conv0_ln_gelu": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "av_lstm_fwd_step": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],

@@ -84,7 +84,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
             for (int e = 0; e < 4; ++e) {
                 const float pv = expf(S[j][e] - m[e]);
                 rs[e] += pv;
-                Pw[(4 * g + e) * LDV + j * 16 + r] = from_f32<T>(pv);
+                float pd = pv;
+                if (p.drop_p > 0.f) {
+                    const unsigned long long idx = (((unsigned long long)b * p.H + h) * p.Tq + (q0 + w * 16 + 4 * g + e)) * p.Tk + (k0 + j * 16 + r);
+                    pd *= drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                }
+                Pw[(4 * g + e) * LDV + j * 16 + r] = from_f32<T>(pd);
             }
         }
 #pragma unroll
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const void* __res
 
 extern "C" int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H, int Tq,
                                 int Tk, int D, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
-                                long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, void* stream) {
+                                long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, float drop_p,
+                                unsigned long long drop_seed, unsigned int drop_stream, void* stream) {
     AV_CHECK(q && k && v && o, "av_attention_fwd: null pointer");
     AV_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0, "av_attention_fwd: bad shape B=%d H=%d Tq=%d Tk=%d", B, H, Tq, Tk);
     AV_CHECK(dtype == AV_F32 || dtype == AV_BF16, "av_attention_fwd: bad dtype %d", dtype);
@@ -221,6 +227,8 @@ extern "C" int av_attention_fwd(const void* q, const void* k, const void* v, voi
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.scale = scale;
+    AV_CHECK(drop_p >= 0.f && drop_p < 1.f, "av_attention_fwd: drop_p=%f out of [0,1)", drop_p);
+    p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_stream = drop_stream;
     const long long es = dtype == AV_F32 ? 4 : 2;
     auto al = [&](const void* ptr, long long bs, long long rs) {
         return ((uintptr_t)ptr % 16 == 0) && ((bs * es) % 16 == 0) && ((rs * es) % 16 == 0) && ((D * es) % 16 == 0);

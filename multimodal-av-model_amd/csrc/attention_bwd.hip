@@ -22,6 +22,9 @@ struct BwdP {
     long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     float scale;
     int vec_ok;
+    float drop_p;
+    unsigned drop_stream;
+    unsigned long long drop_seed;
 };
 
 // delta[b][h][t] = sum_d dO o O.  One wavefront per (b, t): the H*D contiguous elements are read with 16-B loads, each lane
@@ -115,8 +118,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const BwdP p) {
             for (int e = 0; e < 4; ++e) {
                 const int key = j0 + w * 16 + 4 * g + e;
                 const float pv = (qok && key < klen) ? expf(st[e] * p.scale - l) : 0.f;
-                const float ds = pv * (dpt[e] - dl) * p.scale;
-                Pme[(4 * g + e) * LDT + qc] = (T)pv;
+                float dm = 1.f;                                     // dropout multiplier of P[q][key] (same mask as the forward)
+                if (p.drop_p > 0.f) {
+                    const unsigned long long idx = (((unsigned long long)b * p.H + h) * p.Tq + (i0 + qc)) * p.Tk + key;
+                    dm = drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                }
+                const float ds = pv * (dpt[e] * dm - dl) * p.scale;
+                Pme[(4 * g + e) * LDT + qc] = (T)(pv * dm);
                 Sme[(4 * g + e) * LDT + qc] = (T)ds;
             }
         }
@@ -197,7 +205,12 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const BwdP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float pv = kok ? expf(st[e] * p.scale - lrow[e]) : 0.f;
-                Sme[(4 * g + e) * LDT + n * 16 + r] = (T)(pv * (dpt[e] - drow[e]) * p.scale);
+                float dm = 1.f;
+                if (p.drop_p > 0.f) {
+                    const unsigned long long idx = (((unsigned long long)b * p.H + h) * p.Tq + (i0 + w * 16 + 4 * g + e)) * p.Tk + (j0 + n * 16 + r);
+                    dm = drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                }
+                Sme[(4 * g + e) * LDT + n * 16 + r] = (T)(pv * (dpt[e] * dm - drow[e]) * p.scale);
             }
         }
         __syncthreads();
@@ -242,7 +255,7 @@ int launch_bwd(const BwdP& p, hipStream_t st) {
 extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                                 float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int D,
                                 const long long* strides /* 16: (bs, rs) of q,k,v,o,dout,dq,dk,dv */, const int* klen, float scale,
-                                void* stream) {
+                                float drop_p, unsigned long long drop_seed, unsigned int drop_stream, void* stream) {
     AV_CHECK(q && k && v && o && dout && lse && delta_ws && dq && dk && dv && strides, "av_attention_bwd: null pointer");
     AV_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0, "av_attention_bwd: bad shape");
     BwdP p;
@@ -254,6 +267,8 @@ extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, con
     p.do_bs = strides[8]; p.do_rs = strides[9]; p.dq_bs = strides[10]; p.dq_rs = strides[11]; p.dk_bs = strides[12]; p.dk_rs = strides[13];
     p.dv_bs = strides[14]; p.dv_rs = strides[15];
     p.scale = scale;
+    AV_CHECK(drop_p >= 0.f && drop_p < 1.f, "av_attention_bwd: drop_p=%f out of [0,1)", drop_p);
+    p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_stream = drop_stream;
     auto al = [&](const void* ptr, long long bs, long long rs) {
         return ((uintptr_t)ptr % 16 == 0) && ((bs * 2) % 16 == 0) && ((rs * 2) % 16 == 0) && ((D * 2) % 16 == 0);
     };

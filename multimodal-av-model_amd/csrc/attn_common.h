@@ -17,6 +17,9 @@ struct AttnP {
     long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
     float scale;
     int vec_ok;
+    float drop_p;                 // attention-probability dropout (hf:457): P*mask/(1-p) feeds PV, the softmax sum is undropped
+    unsigned drop_stream;
+    unsigned long long drop_seed;
 };
 
 template <typename T> __device__ __forceinline__ void zero16(T* dst) { *(uint4*)dst = make_uint4(0, 0, 0, 0); }

@@ -90,4 +90,40 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- counter-based RNG (Philox4x32-10) for dropout: the mask of element `idx` of stream `stream` under `seed` is a pure
+// function of (seed, stream, idx), so the backward pass regenerates exactly the forward's mask without storing it.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// uniform in [0,1) for element idx (one Philox block per 4 consecutive elements)
+__device__ __forceinline__ float drop_uniform(unsigned long long seed, unsigned stream, unsigned long long idx) {
+    unsigned o[4];
+    const unsigned long long blk = idx >> 2;
+    philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+    return (float)(o[idx & 3] >> 8) * (1.0f / 16777216.0f);
+}
+// multiplier of element idx: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float drop_mult(unsigned long long seed, unsigned stream, unsigned long long idx, float p, float inv_keep) {
+    return drop_uniform(seed, stream, idx) >= p ? inv_keep : 0.f;
+}
+// out-of-line form for epilogues that are fully unrolled over accumulator registers (keeps the unrolled code small)
+__device__ __noinline__ float drop_mult_call(unsigned long long seed, unsigned stream, unsigned long long idx, float p, float inv_keep) {
+    return drop_mult(seed, stream, idx, p, inv_keep);
+}
+// 4 consecutive elements starting at a multiple of 4 (one Philox call)
+__device__ __forceinline__ void drop_mult4(unsigned long long seed, unsigned stream, unsigned long long idx4, float p, float inv_keep, float (&m)[4]) {
+    unsigned o[4];
+    const unsigned long long blk = idx4 >> 2;
+    philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = ((float)(o[i] >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.f;
+}
+
 static inline int av_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

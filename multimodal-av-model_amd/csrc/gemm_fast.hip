@@ -225,6 +225,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
                 for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_fast(ld_any(p.aux, off + e, p.aux_dtype));
             }
         }
+        if (p.drop_p > 0.f) {                                   // off is a multiple of 4 whenever ldc % 4 == 0 (gn % 8 == 0)
+            const float ik = 1.0f / (1.0f - p.drop_p);
+            if ((off & 3) == 0) {
+                float m4[4];
+                drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= m4[e];
+                drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off + 4, p.drop_p, ik, m4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 + e] *= m4[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
+            }
+        }
         if (R) {
             const long long roff = (long long)gm * p.ldr + gn;
             if (full && fl.r_vec) {

@@ -329,6 +329,30 @@ __global__ void mul_scalar_dev_kernel(const float* __restrict__ x, const float* 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = s * x[i];
 }
 
+__global__ void cast_dropout_kernel(const void* __restrict__ x, int xdt, void* __restrict__ y, int ydt, long long n, float p, float inv_keep,
+                                    unsigned long long seed, unsigned stream_id) {
+    const long long n4 = (n + 3) / 4;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        float m[4];
+        drop_mult4(seed, stream_id, (unsigned long long)q * 4, p, inv_keep, m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long i = q * 4 + e;
+            if (i < n) st_any(y, i, ydt, ld_any(x, i, xdt) * m[e]);
+        }
+    }
+}
+__global__ void dropout_uniform_kernel(float* __restrict__ u, long long n, unsigned long long seed, unsigned stream_id) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        u[i] = drop_uniform(seed, stream_id, (unsigned long long)i);
+}
+__global__ void overwrite_rows_kernel(void* __restrict__ x, int xdt, const unsigned char* __restrict__ mask, const float* __restrict__ embed,
+                                      long long rows, int cols) {
+    const long long n = rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (mask[i / cols]) st_any(x, i, xdt, embed[i % cols]);
+}
+
 inline int ew_grid(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -460,6 +484,32 @@ extern "C" int av_mul_scalar_dev(const float* x, const float* scalar, float* y, 
     AV_CHECK(x && scalar && y, "av_mul_scalar_dev: null pointer");
     if (n == 0) return AV_OK;
     hipLaunchKernelGGL(mul_scalar_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, scalar, y, n);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_cast_dropout(const void* x, int xdt, void* y, int ydt, long long n, float p, unsigned long long seed, unsigned int stream_id,
+                               void* stream) {
+    AV_CHECK(x && y, "av_cast_dropout: null pointer");
+    AV_CHECK(p >= 0.f && p < 1.f, "av_cast_dropout: p=%f out of [0,1)", p);
+    if (n == 0) return AV_OK;
+    if (p == 0.f) return av_cast(x, xdt, y, ydt, n, stream);
+    hipLaunchKernelGGL(cast_dropout_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, xdt, y, ydt, n, p, 1.0f / (1.0f - p), seed,
+                       stream_id);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_dropout_uniform(float* u, long long n, unsigned long long seed, unsigned int stream_id, void* stream) {
+    AV_CHECK(u != nullptr, "av_dropout_uniform: null pointer");
+    if (n == 0) return AV_OK;
+    hipLaunchKernelGGL(dropout_uniform_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, u, n, seed, stream_id);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_overwrite_rows(void* x, int xdt, const unsigned char* mask, const float* embed, long long rows, int cols, void* stream) {
+    AV_CHECK(x && mask && embed && cols > 0, "av_overwrite_rows: bad args");
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(overwrite_rows_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, xdt, mask, embed, rows, cols);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

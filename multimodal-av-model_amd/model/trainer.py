@@ -4,9 +4,9 @@ Same constructor arguments and attributes (.visual_encoder .audio_encoder .fusio
 .device .tokenizer), ``train_epoch(loader) -> float``, ``evaluate(loader) -> (loss, wer)``, ``ctc_decode(ids)``.
 Differences that do not change results:
   * compute runs in the package precision mode (bf16 perf / fp32 parity) instead of fp16 autocast + GradScaler;
-  * attn_mask1 == attn_mask2 always, so the audio encoder runs ONCE per step by default
-    (``audio_passes=2`` restores the reference's duplicated pass); dropout / LayerDrop / SpecAugment of wav2vec2
-    are not implemented yet, so the two passes would be bit-identical;
+  * attn_mask1 == attn_mask2 always, so with every stochastic regulariser of wav2vec2 at 0 the two audio
+    passes of the reference are bit-identical and the encoder runs ONCE; as soon as dropout / LayerDrop / SpecAugment
+    are active in train mode it runs twice with independent masks, as the reference does (``audio_passes`` forces it);
   * the class counts of the contrastive loss are taken from the CPU masks (no host sync);
   * optional data parallelism: bucketed gradient all-reduce over RCCL overlapped with the audio backward.
 """
@@ -44,7 +44,7 @@ def word_error_rate(refs, hyps) -> float:
 
 class MultimodalTrainer:
     def __init__(self, visual_encoder, audio_encoder, fusion_module, decoder1, tokenizer, learning_rate=1e-4, device="cuda",
-                 lambda_=0.1, audio_passes: int = 1, reducer: Optional[GradBucketReducer] = None, pair_batched: bool = True,
+                 lambda_=0.1, audio_passes: Optional[int] = None, reducer: Optional[GradBucketReducer] = None, pair_batched: bool = True,
                  visual_side_stream: bool = True):
         self.visual_encoder = visual_encoder.to(device)
         self.audio_encoder = audio_encoder.to(device)
@@ -123,7 +123,12 @@ class MultimodalTrainer:
             vf2 = self.visual_encoder(d["lip2"])
         attn1 = d["mask1"] != 3
         a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1)
-        if self.audio_passes == 2:
+        passes = self.audio_passes
+        if passes is None:      # auto: the duplicate pass only differs when a stochastic regulariser is active in train mode
+            cfg = getattr(self.audio_encoder.model, "cfg", {})
+            knobs = ("hidden_dropout", "attention_dropout", "activation_dropout", "feat_proj_dropout", "layerdrop", "mask_time_prob")
+            passes = 2 if (self.audio_encoder.training and any(cfg.get(k, 0) > 0 for k in knobs)) else 1
+        if passes == 2:
             a2, mid2 = self.audio_encoder(d["audio"], attention_mask=(d["mask2"] != 3))
         else:
             a2, mid2 = a1, mid1

@@ -74,6 +74,42 @@ def conv_out_lengths(cfg: dict, n):
     return n
 
 
+STOCHASTIC_DEFAULTS = dict(hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0,
+                           mask_time_prob=0.0, mask_time_length=10, mask_time_min_masks=2, mask_feature_prob=0.0)
+# dropout streams: layer*8 + site; sites 0 attention-out, 1 FFN activation, 2 FFN out, 3 attention probabilities
+S_FEATPROJ, S_POS = 0xF0000001, 0xF0000002
+
+
+def specaugment_mask(batch: int, seq_len: int, mask_prob: float, mask_length: int, lengths, min_masks: int):
+    """Time-mask spans of SpecAugment as HF draws them (hf:101-217 `_compute_mask_indices`): same numpy-global-RNG call
+    sequence (one `rand`, then one `choice(..., replace=False)` per item), so a given `np.random.seed` gives the same mask."""
+    import numpy as np
+    if mask_length < 1 or mask_length > seq_len:
+        raise ValueError(f"mask_length={mask_length} must be in [1, {seq_len}]")
+    eps = np.random.rand(1).item()
+
+    def nspans(L):
+        n = max(int(mask_prob * L / mask_length + eps), min_masks)
+        if n * mask_length > seq_len:
+            n = seq_len // mask_length
+        if L - (mask_length - 1) < n:
+            n = max(L - (mask_length - 1), 0)
+        return n
+
+    mask = np.zeros((batch, seq_len), dtype=bool)
+    max_n = nspans(seq_len)
+    if max_n == 0:
+        return mask
+    for b, L in enumerate(lengths):
+        n = nspans(int(L))
+        idx = np.random.choice(np.arange(int(L) - (mask_length - 1)), n, replace=False)
+        dummy = seq_len - 1 if len(idx) == 0 else int(idx[0])
+        for s0 in list(idx) + [dummy] * (max_n - n):
+            for o in range(mask_length):
+                mask[b, min(int(s0) + o, seq_len - 1)] = True
+    return mask
+
+
 class _Cache:
     """Compute-dtype copies / re-layouts of parameters, refreshed when the parameter is updated in place."""
 
@@ -197,6 +233,17 @@ class Wav2Vec2ModelHIP(nn.Module):
         Hd, nh = cfg["hidden_size"], cfg["num_attention_heads"]
         hd = Hd // nh
         nl = cfg["num_hidden_layers"]
+        # train-mode stochastic regularisers of wav2vec2 (hf:701,774,1272-1316); all probabilities default to 0
+        sc = {k: cfg.get(k, v) for k, v in STOCHASTIC_DEFAULTS.items()}
+        tm = self.training
+        if tm and sc["mask_feature_prob"] > 0:
+            raise NotImplementedError("SpecAugment feature-axis masking (mask_feature_prob) is not built; set it to 0")
+        hd_p = sc["hidden_dropout"] if tm else 0.0
+        at_p = sc["attention_dropout"] if tm else 0.0
+        ac_p = sc["activation_dropout"] if tm else 0.0
+        fp_p = sc["feat_proj_dropout"] if tm else 0.0
+        ld_p = sc["layerdrop"] if tm else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (hd_p or at_p or ac_p or fp_p) else 0
         wav = wav.contiguous().float()
         feats = self.features(wav, dtype)
         B, T, C = feats.shape
@@ -209,6 +256,14 @@ class Wav2Vec2ModelHIP(nn.Module):
                               self.P("feature_projection.layer_norm.bias").data, out_dtype=dtype, eps=eps)
         h = ops.linear(x, self.c("feature_projection.projection.weight", dtype), self.P("feature_projection.projection.bias").data,
                        out_dtype=torch.float32)
+        if fp_p > 0:
+            h = ops.cast_dropout(h, torch.float32, (fp_p, seed, S_FEATPROJ))             # hf:433
+        if tm and sc["mask_time_prob"] > 0 and cfg.get("apply_spec_augment", True):      # hf:1272-1296 (host numpy RNG, as HF)
+            lengths = n.tolist() if attention_mask is not None else [T] * B
+            sm = specaugment_mask(B, T, sc["mask_time_prob"], sc["mask_time_length"], lengths, sc["mask_time_min_masks"])
+            smt = torch.from_numpy(sm.astype("uint8")).to(dev)
+            L.check(L.lib().av_overwrite_rows(ops.ptr(h), ops.dt(h), ops.ptr(smt), ops.ptr(self.P("masked_spec_embed").data), B * T, Hd,
+                                              ops.stream()), "av_overwrite_rows")
         if keep is not None:
             ops.mask_rows_(h, keep)                                                      # hf:752-755
         # positional conv (grouped, k taps) as an implicit-im2col GEMM per group, + bias, GELU, + residual
@@ -222,6 +277,8 @@ class Wav2Vec2ModelHIP(nn.Module):
                  bias=self.P("encoder.pos_conv_embed.conv.bias").data, act=L.ACT_GELU, R=h, ldr=Hd, batch=G, sA=Cg, sB=Cg * kp * Cg,
                  sC=Cg, sR=Cg, sBias=Cg)
         h = hs0
+        if hd_p > 0:
+            h = ops.cast_dropout(h, torch.float32, (hd_p, seed, S_POS))                  # hf:765
         train = self.trainable_layers() if save else [False] * nl
         first = train.index(True) if any(train) else nl
         mid = torch.zeros_like(h) if nl >= 10 else None
@@ -232,19 +289,25 @@ class Wav2Vec2ModelHIP(nn.Module):
                 ops.axpby(0.25, h, 1.0, mid)                                             # model/encoder.py:97-99
             p = f"encoder.layers.{li}."
             keep_ctx = save and li >= first
+            if ld_p > 0 and float(torch.rand([])) < ld_p:                                # LayerDrop (hf:774-789): identity layer
+                if keep_ctx:
+                    saved[li] = "skipped"
+                continue
             x1, mu1, rs1 = ops.layernorm_fwd(h, self.P(p + "layer_norm.weight").data, self.P(p + "layer_norm.bias").data,
                                              out_dtype=dtype, eps=eps, save_stats=True)
             qkv = ops.linear(x1, self.qkv_w(li, dtype), self.qkv_b(li), out_dtype=dtype).view(B, T, 3, nh, hd)
-            ao, lse = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], klen, scale, need_lse=keep_ctx)
+            ao, lse = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], klen, scale, need_lse=keep_ctx,
+                                        drop=(at_p, seed, li * 8 + 3))
             h2 = ops.linear(ao.view(B, T, Hd), self.c(p + "attention.out_proj.weight", dtype), self.P(p + "attention.out_proj.bias").data,
-                            out_dtype=torch.float32, R=h)
+                            out_dtype=torch.float32, R=h, drop=(hd_p, seed, li * 8 + 0))
             x2, mu2, rs2 = ops.layernorm_fwd(h2, self.P(p + "final_layer_norm.weight").data, self.P(p + "final_layer_norm.bias").data,
                                              out_dtype=dtype, eps=eps, save_stats=True)
             u = torch.empty((B, T, cfg["intermediate_size"]), dtype=dtype, device=dev) if keep_ctx else None
             g = ops.linear(x2, self.c(p + "feed_forward.intermediate_dense.weight", dtype),
-                           self.P(p + "feed_forward.intermediate_dense.bias").data, out_dtype=dtype, act=L.ACT_GELU, C2=u)
+                           self.P(p + "feed_forward.intermediate_dense.bias").data, out_dtype=dtype, act=L.ACT_GELU, C2=u,
+                           drop=(ac_p, seed, li * 8 + 1))
             h3 = ops.linear(g, self.c(p + "feed_forward.output_dense.weight", dtype), self.P(p + "feed_forward.output_dense.bias").data,
-                            out_dtype=torch.float32, R=h2)
+                            out_dtype=torch.float32, R=h2, drop=(hd_p, seed, li * 8 + 2))
             if keep_ctx:
                 tr = train[li]
                 saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, lse=lse, h2=h2, mu2=mu2, rs2=rs2, u=u,
@@ -256,7 +319,8 @@ class Wav2Vec2ModelHIP(nn.Module):
             mid = torch.zeros_like(last)
         ctx = None
         if save and first < nl:
-            ctx = dict(saved=saved, hL=h, muf=muf, rsf=rsf, klen=klen, first=first, train=train, B=B, T=T, dtype=dtype)
+            ctx = dict(saved=saved, hL=h, muf=muf, rsf=rsf, klen=klen, first=first, train=train, B=B, T=T, dtype=dtype,
+                       seed=seed, hd_p=hd_p, at_p=at_p, ac_p=ac_p)
         return last, mid, ctx
 
     # ---- backward --------------------------------------------------------------------------------------------
@@ -280,16 +344,20 @@ class Wav2Vec2ModelHIP(nn.Module):
             if dmid_c is not None and 6 <= li + 1 <= 9 and li + 1 < nl:
                 ops.axpby(0.25, dmid_c, 1.0, dh)
             s = ctx["saved"][li]
+            if isinstance(s, str):                                   # LayerDrop skipped this layer: identity
+                continue
             tr = ctx["train"][li]
             p = f"encoder.layers.{li}."
             M = B * T
+            seed, hd_p, at_p, ac_p = ctx["seed"], ctx["hd_p"], ctx["at_p"], ctx["ac_p"]
             dh3 = dh
-            dh3_t = ops.cast(dh3, dtype)
+            dh3_t = ops.cast_dropout(dh3, dtype, (hd_p, seed, li * 8 + 2))       # the FFN-output dropout mask of the forward
             W2 = self.c(p + "feed_forward.output_dense.weight", dtype)            # [Hd, I]
-            du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I), b_is_weight=True)
+            du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I), b_is_weight=True,
+                               drop=(ac_p, seed, li * 8 + 1))
             if tr:
                 grads[p + "feed_forward.output_dense.weight"] = ops.matmul_tn(dh3_t.view(M, Hd), s["g"].view(M, I))
-                grads[p + "feed_forward.output_dense.bias"] = ops.colsum(dh3.view(M, Hd))
+                grads[p + "feed_forward.output_dense.bias"] = ops.colsum((dh3_t if hd_p > 0 else dh3).view(M, Hd))
             W1 = self.c(p + "feed_forward.intermediate_dense.weight", dtype)      # [I, Hd]
             dx2 = ops.matmul_nn(du, W1, out_dtype=dtype, b_is_weight=True)
             if tr:
@@ -301,16 +369,16 @@ class Wav2Vec2ModelHIP(nn.Module):
                 dh2, grads[p + "final_layer_norm.weight"], grads[p + "final_layer_norm.bias"] = r
             else:
                 dh2 = r
-            dh2_t = ops.cast(dh2, dtype)
+            dh2_t = ops.cast_dropout(dh2, dtype, (hd_p, seed, li * 8 + 0))
             Wo = self.c(p + "attention.out_proj.weight", dtype)
             dao = ops.matmul_nn(dh2_t.view(M, Hd), Wo, out_dtype=dtype, b_is_weight=True).view(B, T, nh, hd)
             if tr:
                 grads[p + "attention.out_proj.weight"] = ops.matmul_tn(dh2_t.view(M, Hd), s["ao"].view(M, Hd))
-                grads[p + "attention.out_proj.bias"] = ops.colsum(dh2.view(M, Hd))
+                grads[p + "attention.out_proj.bias"] = ops.colsum((dh2_t if hd_p > 0 else dh2).view(M, Hd))
             qkv = s["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dao, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx["klen"], scale,
-                              o=s["ao"], lse=s["lse"])
+                              o=s["ao"], lse=s["lse"], drop=(at_p, seed, li * 8 + 3))
             dx1 = ops.matmul_nn(dqkv.view(M, 3 * Hd), self.qkv_w(li, dtype), out_dtype=dtype, b_is_weight=True)
             if tr:
                 dW = ops.matmul_tn(dqkv.view(M, 3 * Hd), s["x1"].view(M, Hd))
@@ -376,4 +444,9 @@ def load_local_config(path: str) -> dict:
         raise NotImplementedError("only the stable-layer-norm / feat_extract_norm='layer' (XLSR) architecture is built")
     keys = ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "conv_dim", "conv_kernel", "conv_stride",
             "num_conv_pos_embeddings", "num_conv_pos_embedding_groups", "layer_norm_eps")
-    return {k: (tuple(c[k]) if isinstance(c[k], list) else c[k]) for k in keys}
+    out = {k: (tuple(c[k]) if isinstance(c[k], list) else c[k]) for k in keys}
+    hf_defaults = dict(hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, feat_proj_dropout=0.0, layerdrop=0.1,
+                       mask_time_prob=0.05, mask_time_length=10, mask_time_min_masks=2, mask_feature_prob=0.0, apply_spec_augment=True)
+    for k, v in hf_defaults.items():          # a real checkpoint trains with its own regularisation settings
+        out[k] = c.get(k, v)
+    return out

@@ -59,7 +59,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
          R: Optional[Tensor] = None, ldr: int = 0, aux: Optional[Tensor] = None, C2: Optional[Tensor] = None,
          stats: Optional[Tensor] = None, alpha: float = 1.0, batch: int = 1, sA: int = 0, sB: int = 0, sC: int = 0,
          sR: int = 0, sBias: int = 0, conv: Optional[dict] = None, a_off: int = 0, b_off: int = 0, c_off: int = 0,
-         batch_inner: int = 0, oA: int = 0, oB: int = 0, oC: int = 0) -> Tensor:
+         batch_inner: int = 0, oA: int = 0, oB: int = 0, oC: int = 0, drop: Optional[tuple] = None) -> Tensor:
     """Raw av_gemm call.  Offsets are in elements."""
     _req(A, "gemm A"); _req(B, "gemm B"); _req(C_, "gemm C")
     if A.dtype != B.dtype:
@@ -75,6 +75,8 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
     a.lda, a.ldb, a.ldc, a.ldr = lda, ldb, ldc, (ldr or ldc)
     a.sA, a.sB, a.sC, a.sR, a.sBias = sA, sB, sC, sR, sBias
     a.batch_inner, a.oA, a.oB, a.oC = batch_inner, oA, oB, oC
+    if drop is not None and drop[0] > 0:
+        a.drop_p, a.drop_seed, a.drop_stream = float(drop[0]), int(drop[1]), int(drop[2])     # (p, seed, stream id)
     a.a_mode, a.b_mode = a_mode, b_mode
     a.in_dtype, a.out_dtype = dt(A), dt(C_)
     a.aux_dtype = dt(aux) if aux is not None else 0
@@ -103,7 +105,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, out_dtype: Optional[torch.dtype] = None,
            act: int = L.ACT_NONE, R: Optional[Tensor] = None, out: Optional[Tensor] = None, C2: Optional[Tensor] = None,
-           aux: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+           aux: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional[tuple] = None) -> Tensor:
     """y[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias)  (nn.Linear layout).  x may be any [..., K] contiguous tensor."""
     K = x.shape[-1]
     M = x.numel() // K
@@ -111,7 +113,7 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, out_dtype: Op
     assert w.shape[1] == K and x.is_contiguous() and w.is_contiguous()
     if out is None:
         out = torch.empty(x.shape[:-1] + (N,), dtype=out_dtype or x.dtype, device=x.device)
-    gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, R=R, aux=aux, C2=C2, alpha=alpha)
+    gemm(x, w, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, R=R, aux=aux, C2=C2, alpha=alpha, drop=drop)
     return out
 
 
@@ -148,7 +150,7 @@ def _fast_ok(t: Tensor, K: int, N: int) -> bool:
 
 def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, act: int = L.ACT_NONE,
               aux: Optional[Tensor] = None, R: Optional[Tensor] = None, out: Optional[Tensor] = None, alpha: float = 1.0,
-              b_is_weight: bool = False) -> Tensor:
+              b_is_weight: bool = False, drop: Optional[tuple] = None) -> Tensor:
     """y[M,N] = a[M,K] @ b[K,N]  (b row-major, e.g. dX = dY @ W with W [N_out,K_in])."""
     K = a.shape[-1]
     M = a.numel() // K
@@ -158,9 +160,9 @@ def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, 
         out = torch.empty(a.shape[:-1] + (N,), dtype=out_dtype or a.dtype, device=a.device)
     if _fast_ok(a, K, N) and K % 64 == 0:
         bt = transpose_cached(b) if b_is_weight else transpose(b)   # [N, K]: K-contiguous operand for the fast kernel
-        gemm(a, bt, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act, aux=aux, R=R, alpha=alpha)
+        gemm(a, bt, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act, aux=aux, R=R, alpha=alpha, drop=drop)
         return out
-    gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_mode=L.B_KN, act=act, aux=aux, R=R, alpha=alpha)
+    gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_mode=L.B_KN, act=act, aux=aux, R=R, alpha=alpha, drop=drop)
     return out
 
 
@@ -248,6 +250,16 @@ def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
     return y
 
 
+def cast_dropout(x: Tensor, dtype: torch.dtype, drop: Optional[tuple]) -> Tensor:
+    """cast(x * mask): ``drop`` = (p, seed, stream id) or None (plain cast)."""
+    if drop is None or drop[0] <= 0:
+        return cast(x, dtype)
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.lib().av_cast_dropout(ptr(x), dt(x), ptr(y), dt(y), x.numel(), float(drop[0]), int(drop[1]), int(drop[2]), stream()), "av_cast_dropout")
+    return y
+
+
 def axpby(a: float, x: Tensor, b: float, y: Tensor) -> Tensor:
     """y = a*x + b*y  (y fp32, in place)."""
     assert x.is_contiguous() and y.is_contiguous() and y.dtype == torch.float32 and x.numel() == y.numel()
@@ -270,21 +282,23 @@ def _chk_view(t: Tensor, name: str):
         raise ValueError(f"{name}: expected a [B,T,H,D] view with contiguous D and head stride D, got {tuple(t.shape)} / {t.stride()}")
 
 
-def attention_fwd(q: Tensor, k: Tensor, v: Tensor, klen: Optional[Tensor], scale: float, need_lse: bool = True):
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, klen: Optional[Tensor], scale: float, need_lse: bool = True,
+                  drop: Optional[tuple] = None):
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk_view(t, n)
     B, Tq, H, D = q.shape
     Tk = k.shape[1]
     o = torch.empty((B, Tq, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if need_lse else None
+    dp, dseed, dstream = (float(drop[0]), int(drop[1]), int(drop[2])) if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
     L.check(L.lib().av_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), dt(q), B, H, Tq, Tk, D,
                                      q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                     o.stride(0), o.stride(1), ptr(klen), scale, stream()), "av_attention_fwd")
+                                     o.stride(0), o.stride(1), ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_fwd")
     return o, lse
 
 
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: Tensor, dv: Tensor, klen: Optional[Tensor],
-                  scale: float, o: Optional[Tensor] = None, lse: Optional[Tensor] = None) -> None:
+                  scale: float, o: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop: Optional[tuple] = None) -> None:
     """Backward of attention_fwd from batched MFMA GEMMs + row kernels (P is re-materialised, T x T is small here):
     P = softmax(scale QK^T); dV = P^T dO; dP = dO V^T; dS = scale P o (dP - rowsum(dP o P)); dQ = dS K; dK = dS^T Q.
     dq/dk/dv are [B,T,H,D] output views (written in place)."""
@@ -292,12 +306,15 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: T
         _chk_view(t, n)
     B, Tq, H, D = q.shape
     Tk = k.shape[1]
+    dp, dseed, dstream = (float(drop[0]), int(drop[1]), int(drop[2])) if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
+    if dp > 0 and not (q.dtype == torch.bfloat16 and o is not None and lse is not None):
+        raise NotImplementedError("attention-probability dropout is implemented in the fused bf16 backward only")
     if q.dtype == torch.bfloat16 and o is not None and lse is not None:     # fused flash-style backward (attention_bwd.hip)
         _chk_view(o, "o")
         st = (C.c_longlong * 16)(*[x for t in (q, k, v, o, do, dq, dk, dv) for x in (t.stride(0), t.stride(1))])
         delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
         L.check(L.lib().av_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                                         B, H, Tq, Tk, D, st, ptr(klen), scale, stream()), "av_attention_bwd")
+                                         B, H, Tq, Tk, D, st, ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_bwd")
         return
     ld = (Tk + 7) // 8 * 8
     dev = q.device

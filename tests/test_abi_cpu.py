@@ -35,7 +35,7 @@ def test_errors_are_reported_not_aborted():
     a.M, a.N, a.K, a.batch = 4, 4, 0, 1
     assert lib.av_gemm(ctypes.byref(a), None) != 0 and b"bad shape" in lib.av_last_error()
     assert lib.av_layernorm_fwd(None, 0, None, None, None, 0, None, None, 1, 8, 1e-5, 0, None) != 0
-    assert lib.av_attention_fwd(16, 16, 16, 16, None, 1, 1, 1, 4, 4, 48, 0, 0, 0, 0, 0, 0, 0, 0, None, 1.0, None) != 0
+    assert lib.av_attention_fwd(16, 16, 16, 16, None, 1, 1, 1, 4, 4, 48, 0, 0, 0, 0, 0, 0, 0, 0, None, 1.0, 0.0, 0, 0, None) != 0
     assert b"head_dim" in lib.av_last_error()
     try:
         L.check(1, "demo")
@@ -55,6 +55,6 @@ def test_gemm_args_struct_matches_header_layout():
         stmt = stmt.strip()
         if not stmt:
             continue
-        stmt = re.sub(r"^(const\s+)?(void|float|int|long long)\s*\*?", "", stmt).strip()
+        stmt = re.sub(r"^(const\s+)?(unsigned\s+long\s+long|unsigned\s+int|long\s+long|void|float|int)\s*\*?", "", stmt).strip()
         fields += [f.strip().lstrip("*").strip() for f in stmt.split(",")]
     assert fields == [f[0] for f in L.GemmArgs._fields_], (fields, [f[0] for f in L.GemmArgs._fields_])

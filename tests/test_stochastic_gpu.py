@@ -1,0 +1,153 @@
+"""Train-mode stochastic regularisers of wav2vec2 on the HIP path: Philox dropout masks (elementwise, GEMM epilogue,
+attention probabilities) are pure functions of (seed, stream, index), so every check is exact against a PyTorch
+reference that uses the SAME mask; LayerDrop / SpecAugment / full-model checks use fixed RNG seeds."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _mask(n, p, seed, stream):
+    L = pkg("_lib"); ops = pkg("ops")
+    u = torch.empty(n, device="cuda")
+    L.check(L.lib().av_dropout_uniform(ops.ptr(u), n, seed, stream, ops.stream()))
+    return (u >= p).float() / (1.0 - p), u
+
+
+def test_dropout_kernel_statistics_and_determinism():
+    ops = pkg("ops")
+    x = torch.randn(1000, 1031, device="cuda")
+    m, u = _mask(x.numel(), 0.1, 1234, 7)
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 2e-3
+    y = ops.cast_dropout(x, torch.float32, (0.1, 1234, 7))
+    torch.testing.assert_close(y, x * m.view_as(x), rtol=0, atol=0)
+    assert abs(float((y == 0).float().mean()) - 0.1) < 3e-3
+    torch.testing.assert_close(ops.cast_dropout(x, torch.float32, (0.1, 1234, 7)), y, rtol=0, atol=0)
+    assert not torch.equal(ops.cast_dropout(x, torch.float32, (0.1, 1235, 7)), y)
+    assert not torch.equal(ops.cast_dropout(x, torch.float32, (0.1, 1234, 8)), y)
+    yb = ops.cast_dropout(x, torch.bfloat16, (0.25, 5, 1))
+    mb, _ = _mask(x.numel(), 0.25, 5, 1)
+    torch.testing.assert_close(yb.float(), (x * mb.view_as(x)).to(torch.bfloat16).float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_dropout_matches_mask(dtype):
+    ops = pkg("ops"); L = pkg("_lib")
+    M, N, K = 300, 256, 128
+    x = (torch.randn(M, K, device="cuda")).to(dtype); w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, device="cuda"); r = torch.randn(M, N, device="cuda")
+    m, _ = _mask(M * N, 0.2, 99, 3)
+    m = m.view(M, N)
+    ref = torch.nn.functional.gelu((x.double() @ w.double().t()).float() + b) * m + r
+    out = ops.linear(x, w, b, out_dtype=torch.float32, act=L.ACT_GELU, R=r, drop=(0.2, 99, 3))
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out, ref, **tol)
+
+
+@pytest.mark.parametrize("B,H,T,D", [(2, 4, 70, 64), (1, 2, 130, 128)])
+def test_attention_dropout_fwd_bwd_same_mask(B, H, T, D):
+    ops = pkg("ops")
+    dtype = torch.bfloat16
+    p_, seed, stream = 0.15, 4242, 11
+    qkv = torch.randn(B, T, 3, H, D, device="cuda").to(dtype)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    scale = D ** -0.5
+    o, lse = ops.attention_fwd(q, k, v, None, scale, drop=(p_, seed, stream))
+    m, _ = _mask(B * H * T * T, p_, seed, stream)
+    m = m.view(B, H, T, T).double()
+    qr, kr, vr = (t.float().permute(0, 2, 1, 3).detach().clone().requires_grad_(True) for t in (q, k, v))
+    P = torch.softmax((qr.double() @ kr.double().transpose(2, 3)) * scale, -1)
+    ref = ((P * m) @ vr.double()).float()
+    torch.testing.assert_close(o.float().permute(0, 2, 1, 3), ref, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(lse, torch.logsumexp((qr.double() @ kr.double().transpose(2, 3)) * scale, -1).float(), rtol=2e-2, atol=5e-2)
+    do = torch.randn(B, T, H, D, device="cuda").to(dtype)
+    ref.backward(do.float().permute(0, 2, 1, 3))
+    dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
+    ops.attention_bwd(q, k, v, do, dq, dk, dv, None, scale, o=o, lse=lse, drop=(p_, seed, stream))
+    for a, g in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad)):
+        torch.testing.assert_close(a.float().permute(0, 2, 1, 3), g, rtol=6e-2, atol=6e-2)
+
+
+def _audio(cfg_extra, precision):
+    init = pkg("utils.init"); enc = pkg("model.encoder"); synth = pkg("dataset.synthetic")
+    pkg("precision").set_precision(precision)
+    cfg = dict(init.W2V2_TINY, **cfg_extra)
+    ae = enc.AudioEncoder(cfg, freeze=True).cuda()
+    ae.load_state_dict(init.w2v2_state_dict(init.W2V2_TINY))
+    for n, p in ae.model.named_parameters():
+        p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
+    batch = synth.make_batch(3, 1.2, seed=42, ragged=True)
+    return ae, batch["audio"].cuda(), (batch["mask1"] != 3).cuda()
+
+
+def test_eval_mode_ignores_stochastic_knobs_and_train_mode_uses_them():
+    knobs = dict(hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, feat_proj_dropout=0.1, layerdrop=0.2,
+                 mask_time_prob=0.3, mask_time_length=5, mask_time_min_masks=1)
+    ae, wav, mask = _audio(knobs, "bf16")
+    ae0, _, _ = _audio({}, "bf16")
+    ae.eval(); ae0.eval()
+    with torch.no_grad():
+        a, _ = ae(wav, mask); b, _ = ae0(wav, mask)
+    assert torch.equal(a, b)                                   # eval: deterministic, identical to the knob-free model
+    ae.train()
+    torch.manual_seed(1); np.random.seed(1)
+    t1, _ = ae(wav, mask)
+    torch.manual_seed(1); np.random.seed(1)
+    t2, _ = ae(wav, mask)
+    torch.manual_seed(2); np.random.seed(2)
+    t3, _ = ae(wav, mask)
+    assert torch.equal(t1, t2) and not torch.equal(t1, t3) and not torch.equal(t1, a)
+    assert torch.isfinite(t1).all()
+    (t1.float() ** 2).mean().backward()
+    g = [p.grad for p in ae.parameters() if p.requires_grad]
+    assert all(x is not None and torch.isfinite(x).all() for x in g)
+
+
+def test_train_mode_gradients_match_directional_derivative():
+    """fp32: with the RNG re-seeded before every forward the masks are identical, so the stochastic model is a fixed
+    differentiable function; its hand-written backward must match a central difference."""
+    knobs = dict(hidden_dropout=0.15, attention_dropout=0.0, activation_dropout=0.1, feat_proj_dropout=0.1, layerdrop=0.15,
+                 mask_time_prob=0.2, mask_time_length=4, mask_time_min_masks=1)
+    ae, wav, mask = _audio(knobs, "fp32")
+    ae.train()
+    g = torch.Generator().manual_seed(0)
+
+    def loss():
+        torch.manual_seed(5); np.random.seed(5)
+        last, mid = ae(wav, mask)
+        return (last * wl).sum() + (mid * wm).sum()
+    torch.manual_seed(5); np.random.seed(5)
+    with torch.no_grad():
+        last, mid = ae(wav, mask)
+    wl = torch.randn(last.shape, generator=g).cuda(); wm = torch.randn(mid.shape, generator=g).cuda()
+    L0 = loss(); L0.backward()
+    params = [p for p in ae.parameters() if p.requires_grad]
+    dirs = [torch.randn(p.shape, generator=g).cuda() * 1e-3 for p in params]
+    analytic = sum(float((p.grad * d).sum()) for p, d in zip(params, dirs) if p.grad is not None)   # LayerDrop-skipped layers: no grad
+    with torch.no_grad():
+        for p, d in zip(params, dirs):
+            p.add_(d)
+        lp = float(loss())
+        for p, d in zip(params, dirs):
+            p.sub_(2 * d)
+        lm = float(loss())
+    numeric = (lp - lm) / 2.0
+    print("directional derivative: analytic", analytic, "numeric", numeric)
+    assert abs(analytic - numeric) < 2e-2 * max(1.0, abs(numeric))
+
+
+def test_specaugment_mask_matches_hf_function():
+    tm = pytest.importorskip("transformers.models.wav2vec2.modeling_wav2vec2")
+    w2 = pkg("model.w2v2")
+    for seed, (B, T, prob, ln, lens, mn) in enumerate([(3, 49, 0.3, 5, [49, 30, 49], 2), (2, 199, 0.05, 10, [199, 150], 2), (4, 60, 0.5, 3, [60, 10, 2, 33], 0)]):
+        np.random.seed(seed); mine = w2.specaugment_mask(B, T, prob, ln, lens, mn)
+        am = torch.zeros(B, T, dtype=torch.long)
+        for i, l in enumerate(lens):
+            am[i, :l] = 1
+        np.random.seed(seed); ref = tm._compute_mask_indices((B, T), prob, ln, attention_mask=am, min_masks=mn)
+        assert (mine == ref).all()
