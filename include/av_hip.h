@@ -143,6 +143,14 @@ int av_lstm_fwd_step(const float* gx, const void* whh, void* hseq, float* cseq, 
 int av_lstm_bwd_step(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgates, const void* whhT,
                      const void* gates, const float* cseq, float* dc, int dtype, int T, int B, int H, int s, void* stream);
 
+/* persistent form (bf16, H = 512): ONE launch per layer for all T steps of both directions; W_hh slices stay in LDS, steps
+ * are separated by a per-direction release/acquire arrival counter (64 resident workgroups, bounded spins: counters[2] is
+ * set on timeout).  counters: 3 ints of workspace.  Same buffers / results as the step kernels. */
+int av_lstm_fwd_layer(const float* gx, const void* whh, void* hseq, float* cseq, void* gates, void* out_bt, int* counters,
+                      int T, int B, int H, void* stream);
+int av_lstm_bwd_layer(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgates, const void* whhT,
+                      const void* gates, const float* cseq, float* dc, int* counters, int T, int B, int H, void* stream);
+
 /* ---- fusion glue without host syncs (model/fusion_module.py:40-55,66; model/trainer.py:98,102) ------------- */
 int av_mask_downsample(const long long* mask, long long* out, int B, int Tin, int Tout, void* stream);
 /* ws_i32: B*Ta + B + groups ints (compaction index, counts, per-group batch max) kept for the backward;

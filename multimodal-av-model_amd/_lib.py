@@ -58,6 +58,8 @@ SIGNATURES = {
     "av_conv0_ln_gelu": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "av_lstm_fwd_step": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "av_lstm_bwd_step": [vp, i32, ll, ll, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "av_lstm_fwd_layer": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "av_lstm_bwd_layer": [vp, i32, ll, ll, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "av_mask_downsample": [vp, vp, i32, i32, i32, vp],
     "av_fusion_gather_lerp_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "av_fusion_gather_lerp_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],

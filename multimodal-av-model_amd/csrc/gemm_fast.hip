@@ -11,6 +11,8 @@
 //   * XCD-aware bijective remap of blockIdx so that tiles sharing an A panel run on one XCD (private L2);
 //   * epilogue through an fp32 LDS image so that bias / GELU / gelu' x aux / residual / C2 and the stores are
 //     16-32 B per lane and row-contiguous.
+#include <cstdlib>
+
 #include "av_common.h"
 
 namespace {
@@ -79,6 +81,81 @@ __device__ __forceinline__ void stage_conv(const bf16_t* __restrict__ base, cons
 }
 
 struct FastFlags { int c_vec, r_vec, aux_vec; };
+
+// shared tail of the coalesced epilogue: optional pre-activation copy, activation, dropout, residual, store (8 columns)
+__device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const FastFlags& fl, float (&v)[8], long long off, int gm, int gn, bool full,
+                                               const float* R) {
+    if (p.C2) {
+        if (full && fl.c_vec) {
+            if (p.out_dtype == AV_BF16) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                *(bf16x8*)((bf16_t*)p.C2 + off) = o;
+            } else {
+                *(f32x4*)((float*)p.C2 + off) = f32x4{v[0], v[1], v[2], v[3]};
+                *(f32x4*)((float*)p.C2 + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C2, off + e, p.out_dtype, v[e]);
+        }
+    }
+    if (p.act == AV_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+    } else if (p.act == AV_ACT_MUL_GELU_GRAD) {
+        if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
+            const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_fast(ld_any(p.aux, off + e, p.aux_dtype));
+        }
+    }
+    if (p.drop_p > 0.f) {
+        const float ik = 1.0f / (1.0f - p.drop_p);
+        if ((off & 3) == 0) {
+            float m4[4];
+            drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= m4[e];
+            drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off + 4, p.drop_p, ik, m4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 + e] *= m4[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
+        }
+    }
+    if (R) {
+        const long long roff = (long long)gm * p.ldr + gn;
+        if (full && fl.r_vec) {
+            const f32x4 r0 = *(const f32x4*)(R + roff), r1 = *(const f32x4*)(R + roff + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += R[roff + e];
+        }
+    }
+    if (full && fl.c_vec) {
+        if (p.out_dtype == AV_BF16) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            *(bf16x8*)((bf16_t*)p.C + off) = o;
+        } else {
+            *(f32x4*)((float*)p.C + off) = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)((float*)p.C + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C, off + e, p.out_dtype, v[e]);
+    }
+}
+
 
 // BNT = 128: waves 2(M) x 2(N), 64 x 64 each.   BNT = 64: waves 4(M) x 1(N), 32 x 64 each (N <= 64 problems:
 // ResNet layer1, grouped positional conv).   CONV: A operand is the implicit im2col of an NHWC image.
@@ -303,6 +380,124 @@ bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2: 256 x 128 x 64 tile, 512 threads = 8 wavefronts (4 x 2, 64 x 64 each), THREE LDS stages with the loads of K-tile
+// t+2 in flight while tile t is multiplied: each wave retires only its OLDEST stage with a counted s_waitcnt vmcnt(N)
+// (N = its LDS-DMA instructions of the newer stage), then ONE raw s_barrier per K-tile publishes the tile and frees the
+// stage read in the previous iteration (read-after-wait-and-barrier / restage-after-barrier: guide §5 "Pipelining across
+// barriers").  144 KiB of LDS => one workgroup per CU, two waves per SIMD.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int V2_BM = 256, V2_BN = 128, V2_NT = 512;
+constexpr int V2_STAGE = (V2_BM + V2_BN) * BK * 2;          // 49 152 B
+constexpr int V2_CLD = V2_BN + 4;
+constexpr int V2_LDS = 3 * V2_STAGE;                        // 147 456 B >= epilogue image 256*132*4 = 135 168 B
+
+__global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
+    const int wrow = (w >> 1) * 64, wcol = (w & 1) * 64;
+    const int r = lane & 15, g = lane >> 4;
+    const int nwg = nbM * nbN;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * nbN;
+    const int grp = bid / per_group, in_grp = bid - grp * per_group;
+    const int first_m = grp * GM;
+    const int gsz = nbM - first_m < GM ? nbM - first_m : GM;
+    const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
+    const int m0 = mb * V2_BM, n0 = nb * V2_BN;
+    const int z = blockIdx.z;
+    const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
+    const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
+    const bf16_t* A = (const bf16_t*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
+    const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per wave and stage: 4 LDS-DMA instructions for A (256 rows / 8 waves / 8 rows) + 2 for B = 6
+    auto stage = [&](int kt, char* buf) {
+        stage_rows<4>(A, p.lda, m0, p.M, kt * BK, buf, w, lane);
+        stage_rows<2>(B, p.ldb, n0, p.N, kt * BK, buf + V2_BM * BK * 2, w, lane);
+    };
+    const int nk = p.K / BK;
+    stage(0, smem);
+    if (nk > 1) stage(1, smem + V2_STAGE);
+
+    const int sw = r & 7;
+    const int a_off = (wrow + r) * 128, b_off = V2_BM * BK * 2 + (wcol + r) * 128;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // my loads of tile kt have landed (tile kt+1 may fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // tile kt complete for everyone; stage (kt-1)%3 is free
+        if (kt + 2 < nk) {
+            int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
+            stage(kt + 2, smem + nxt * V2_STAGE);
+        }
+        const char* ab = smem + cur * V2_STAGE + a_off;
+        const char* bb = smem + cur * V2_STAGE + b_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int choff = ((ks * 4 + g) ^ sw) << 4;
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(ab + i * 16 * 128 + choff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(bb + j * 16 * 128 + choff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        cur = cur + 1 == 3 ? 0 : cur + 1;
+    }
+    __syncthreads();                                         // every wave is done reading the last stage
+
+    float* cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                cs[(wrow + i * 16 + 4 * g + e) * V2_CLD + wcol + j * 16 + r] = acc[i][j][e] * p.alpha;
+    __syncthreads();
+
+    const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
+    const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
+    const float* bias = p.bias ? p.bias + (long long)zi * p.sBias : nullptr;
+    constexpr int CPR = V2_BN / 8;
+    float bv[8];
+    {
+        const int gnt = n0 + (tid % CPR) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (bias && gnt + e < p.N) ? bias[gnt + e] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < V2_BM * CPR / V2_NT; ++it) {
+        const int id = it * V2_NT + tid;
+        const int row = id / CPR, cc = (id % CPR) * 8;
+        const int gm = m0 + row, gn = n0 + cc;
+        if (gm >= p.M || gn >= p.N) continue;
+        float v[8];
+        const f32x4 v0 = *(const f32x4*)(cs + row * V2_CLD + cc), v1 = *(const f32x4*)(cs + row * V2_CLD + cc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
+        const bool full = gn + 8 <= p.N;
+        const long long off = cbase + (long long)gm * p.ldc + gn;
+        epilogue_store(p, fl, v, off, gm, gn, full, R);
+    }
+}
+
 template <int BNT, bool CONV>
 int launch_fast(const av_gemm_args& p, hipStream_t st, const FastFlags& fl) {
     constexpr int STAGE = TILE_A + BNT * BK * 2;
@@ -343,6 +538,21 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     const long long aes = p.aux_dtype == AV_F32 ? 4 : 2;
     fl.aux_vec = p.aux && al16(p.aux) && (p.ldc * aes) % 16 == 0 && (p.sC * aes) % 16 == 0 && (p.oC * aes) % 16 == 0;
     const bool narrow = p.N <= 64;
+    static const int v2_mode = [] { const char* e = getenv("AVAMD_GEMM_V2"); return e ? atoi(e) : 0; }();   // measured: not faster at M~6k, K=1k
+    if (!conv && !narrow && v2_mode && p.M >= 512) {
+        static bool v2_attr = false;
+        if (!v2_attr) {
+            if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS) != hipSuccess) {
+                av_set_error("av_gemm(fast v2): cannot raise dynamic LDS to %d", V2_LDS);
+                return AV_ERR_LAUNCH;
+            }
+            v2_attr = true;
+        }
+        const int nbM = av_cdiv(p.M, V2_BM), nbN = av_cdiv(p.N, V2_BN);
+        hipLaunchKernelGGL(gemm_nt_bf16_v2_kernel, dim3((unsigned)(nbM * (long long)nbN), 1, (unsigned)p.batch), dim3(V2_NT), V2_LDS, st, p, nbM, nbN, fl);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
     if (conv) return narrow ? launch_fast<64, true>(p, st, fl) : launch_fast<128, true>(p, st, fl);
     return narrow ? launch_fast<64, false>(p, st, fl) : launch_fast<128, false>(p, st, fl);
 }

@@ -1,0 +1,311 @@
+// Persistent BiLSTM layer for the bf16 perf path (H = 512): ONE launch runs all T time steps of both directions.
+// 64 workgroups (2 directions x 32 tiles of 16 hidden units) stay resident; each keeps its W_hh slice (forward:
+// 4 gates x 16 units x 512, backward: 16 units x 2048 of W_hh^T; 64 KiB bf16) in LDS for the whole sequence, so a
+// step only moves h_{t-1} (forward) / dgates_{t+-1} (backward) through L2.  Steps are separated by a per-direction
+// arrival counter: producer = every wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane
+// agent-scope release + relaxed atomic add; consumer = ONE lane polls relaxed (s_sleep), agent-scope acquire,
+// workgroup barrier, then plain loads (guide G16 counter form).  Spins are bounded: on timeout a flag is raised and
+// the kernel still terminates.  Arithmetic, buffers and results are identical to the per-step kernels of lstm.hip
+// (which remain the fp32 / generic path).
+#include "av_common.h"
+
+namespace {
+
+constexpr int H = 512, NJT = H / 16;       // 32 unit tiles per direction
+constexpr int MAXMT = 4;
+constexpr int WLD = H + 8;                 // forward W slice row (bf16 elements): 64 rows x 520
+constexpr int WTLD = 4 * H + 8;            // backward W^T slice row: 16 rows x 2056
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+struct PF {
+    const float* gx; const bf16_t* whh; bf16_t* hseq; float* cseq; bf16_t* gates; bf16_t* out_bt;
+    int* counters;       // [2] arrivals per direction, [2] = timeout flag
+    int T, B;
+};
+struct PB {
+    const void* dout; int dout_dtype; long long do_bs, do_ts;
+    bf16_t* dgates; const bf16_t* whhT; const bf16_t* gates; const float* cseq; float* dc;
+    int* counters;
+    int T, B;
+};
+
+__device__ __forceinline__ void publish(int* counter, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every wave: my stores have left
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void wait_for(int* counter, int target, int* flag, int tid) {
+    if (tid == 0) {
+        unsigned spins = 0;
+        const bool dead = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // after a timeout: never spin again
+        while (!dead && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+constexpr int ALD = H + 8;                  // forward A tile row (64 rows x 520 bf16)
+constexpr int BCH = 256, BLD = BCH + 8;     // backward A chunk: 64 rows x 256 of K = 4H, double buffered
+
+__global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Wl = (bf16_t*)smem;                                      // [64][WLD]: row q*16+u = gate q, unit j0+u
+    bf16_t* Al = Wl + 64 * WLD;                                      // [64][ALD]: h_{t-1} rows of the current 64-row group
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int d = blockIdx.y, j0 = blockIdx.x * 16;
+    const int B = p.B, T = p.T;
+    const bf16_t* W = p.whh + (long long)d * 4 * H * H;
+    for (int i = tid; i < 64 * (H / 8); i += 256) {                  // W_hh slice -> LDS (16 B per thread)
+        const int row = i / (H / 8), ch = i % (H / 8);
+        const int q = row >> 4, u = row & 15;
+        *(uint4*)(Wl + row * WLD + ch * 8) = *(const uint4*)(W + (long long)(q * H + j0 + u) * H + ch * 8);
+    }
+    __syncthreads();
+    int* cnt = p.counters + d;
+    const int j = j0 + r;
+    for (int s = 0; s < T; ++s) {
+        const int td = d == 0 ? s : T - 1 - s;
+        const int tp = d == 0 ? td - 1 : td + 1;
+        // step-local operands do not depend on other workgroups: issue their loads BEFORE the wait so that the HBM
+        // latency overlaps the hand-off (first row group; further row groups load in place)
+        float pgx[4][4], pcp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = w * 16 + 4 * g + e;
+            const bool ok = row < B;
+            const float* gxr = p.gx + (((long long)td * B + (ok ? row : 0)) * 2 + d) * 4 * H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pgx[e][q] = ok ? gxr[q * H + j] : 0.f;
+            pcp[e] = (ok && s > 0) ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;        // my own earlier store
+        }
+        if (s > 0) wait_for(cnt, NJT * s, p.counters + 2, tid);      // every tile of my direction finished step s-1
+        for (int mbase = 0; mbase < B; mbase += 64) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s > 0) {
+                // h_{t-1}[mbase .. mbase+64) x 512 -> LDS, fully coalesced (one 1-KiB row per 64 lanes)
+                const bf16_t* hprev = p.hseq + ((long long)tp * B) * 2 * H + d * H;
+#pragma unroll
+                for (int it = 0; it < 64 * (H / 8) / 256; ++it) {
+                    const int i = it * 256 + tid;
+                    const int row = i / (H / 8), ch = i % (H / 8);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (mbase + row < B) v = *(const uint4*)(hprev + (long long)(mbase + row) * 2 * H + ch * 8);
+                    *(uint4*)(Al + row * ALD + ch * 8) = v;
+                }
+                __syncthreads();
+                const bf16_t* arow = Al + (w * 16 + r) * ALD + 8 * g;          // wave w = row tile w, full K
+#pragma unroll
+                for (int kk = 0; kk < H / 32; ++kk) {
+                    const bf16x8 a = *(const bf16x8*)(arow + kk * 32);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bf16x8 bq = *(const bf16x8*)(Wl + (q * 16 + r) * WLD + kk * 32 + 8 * g);
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc[q], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = mbase + w * 16 + 4 * g + e;
+                if (row < B) {
+                    float gxv[4], cprev;
+                    if (mbase == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gxv[q] = pgx[e][q];
+                        cprev = pcp[e];
+                    } else {
+                        const float* gxr = p.gx + (((long long)td * B + row) * 2 + d) * 4 * H;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gxv[q] = gxr[q * H + j];
+                        cprev = s > 0 ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;
+                    }
+                    const float ig = sigmoid_f(acc[0][e] + gxv[0]);
+                    const float fg = sigmoid_f(acc[1][e] + gxv[1]);
+                    const float gg = tanhf(acc[2][e] + gxv[2]);
+                    const float og = sigmoid_f(acc[3][e] + gxv[3]);
+                    const float c = fg * cprev + ig * gg;
+                    const float h = og * tanhf(c);
+                    p.cseq[(((long long)td * B + row) * 2 + d) * H + j] = c;
+                    p.hseq[((long long)td * B + row) * 2 * H + d * H + j] = (bf16_t)h;
+                    if (p.out_bt) p.out_bt[((long long)row * T + td) * 2 * H + d * H + j] = (bf16_t)h;
+                    if (p.gates) {
+                        bf16_t* go = p.gates + (((long long)td * B + row) * 2 + d) * 4 * H;
+                        go[j] = (bf16_t)ig; go[H + j] = (bf16_t)fg; go[2 * H + j] = (bf16_t)gg; go[3 * H + j] = (bf16_t)og;
+                    }
+                }
+            }
+            __syncthreads();                                         // Al is rewritten by the next row group / step
+        }
+        if (s + 1 < T) publish(cnt, tid);
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Wt = (bf16_t*)smem;                                      // [16][WTLD]: row u = unit j0+u, k over the 4H gate rows
+    bf16_t* Ab = Wt + 16 * WTLD;                                     // [2][64][BLD]: K-chunks of dgates[t_next]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int d = blockIdx.y, j0 = blockIdx.x * 16;
+    const int B = p.B, T = p.T;
+    const bf16_t* W = p.whhT + (long long)d * H * 4 * H;
+    for (int i = tid; i < 16 * (4 * H / 8); i += 256) {
+        const int row = i / (4 * H / 8), ch = i % (4 * H / 8);
+        *(uint4*)(Wt + row * WTLD + ch * 8) = *(const uint4*)(W + (long long)(j0 + row) * 4 * H + ch * 8);
+    }
+    __syncthreads();
+    int* cnt = p.counters + d;
+    const int j = j0 + r;
+    constexpr int NCH = 4 * H / BCH;                                 // 8 chunks
+    constexpr int CPT = 64 * (BCH / 8) / 256;                        // 16-B pieces per thread per chunk = 8
+    for (int s = 0; s < T; ++s) {
+        const int td = d == 0 ? T - 1 - s : s;
+        const int tn = d == 0 ? td + 1 : td - 1;
+        const int tp = d == 0 ? td - 1 : td + 1;
+        float pdo[4], pg[4][4], pc[4], pcp[4], pdc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                // step-local operands of the first row group, before the wait
+            const int row = w * 16 + 4 * g + e;
+            const bool ok = row < B;
+            const int rr = ok ? row : 0;
+            pdo[e] = ok ? ld_any(p.dout, (long long)rr * p.do_bs + (long long)td * p.do_ts + d * H + j, p.dout_dtype) : 0.f;
+            const bf16_t* gs = p.gates + (((long long)td * B + rr) * 2 + d) * 4 * H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pg[e][q] = ok ? (float)gs[q * H + j] : 0.f;
+            pc[e] = ok ? p.cseq[(((long long)td * B + rr) * 2 + d) * H + j] : 0.f;
+            const bool has_prev = d == 0 ? td > 0 : td < T - 1;
+            pcp[e] = (ok && has_prev) ? p.cseq[(((long long)tp * B + rr) * 2 + d) * H + j] : 0.f;
+            pdc[e] = (ok && s > 0) ? p.dc[((long long)d * B + rr) * H + j] : 0.f;                        // my own earlier store
+        }
+        if (s > 0) wait_for(cnt, NJT * s, p.counters + 2, tid);
+        for (int mbase = 0; mbase < B; mbase += 64) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s > 0) {                                            // dh_rec = dgates[tn] x W_hh, K = 4H in 8 double-buffered chunks
+                const bf16_t* A = p.dgates + (((long long)tn * B) * 2 + d) * 4 * H;          // row stride 8H
+                uint4 st[CPT];
+                auto gload = [&](int c) {
+#pragma unroll
+                    for (int it = 0; it < CPT; ++it) {
+                        const int i = it * 256 + tid;
+                        const int row = i / (BCH / 8), ch = i % (BCH / 8);
+                        st[it] = make_uint4(0, 0, 0, 0);
+                        if (mbase + row < B) st[it] = *(const uint4*)(A + (long long)(mbase + row) * 8 * H + c * BCH + ch * 8);
+                    }
+                };
+                auto lstore = [&](int buf) {
+#pragma unroll
+                    for (int it = 0; it < CPT; ++it) {
+                        const int i = it * 256 + tid;
+                        const int row = i / (BCH / 8), ch = i % (BCH / 8);
+                        *(uint4*)(Ab + (buf * 64 + row) * BLD + ch * 8) = st[it];
+                    }
+                };
+                gload(0);
+                lstore(0);
+                __syncthreads();
+#pragma unroll 1
+                for (int c = 0; c < NCH; ++c) {
+                    const int cur = c & 1;
+                    if (c + 1 < NCH) gload(c + 1);                  // global loads in flight during the MFMAs of chunk c
+                    const bf16_t* arow = Ab + (cur * 64 + w * 16 + r) * BLD + 8 * g;
+                    const bf16_t* brow = Wt + r * WTLD + c * BCH + 8 * g;
+#pragma unroll
+                    for (int kk = 0; kk < BCH / 32; ++kk) {
+                        const bf16x8 a = *(const bf16x8*)(arow + kk * 32);
+                        const bf16x8 bq = *(const bf16x8*)(brow + kk * 32);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc, 0, 0, 0);
+                    }
+                    if (c + 1 < NCH) lstore(cur ^ 1);               // buffer cur^1 was last read in iteration c-1 (barrier below)
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = mbase + w * 16 + 4 * g + e;
+                if (row < B) {
+                    float dh, ig, fg, gg, og, c, cprev, dcold;
+                    float* dcp = p.dc + ((long long)d * B + row) * H + j;
+                    if (mbase == 0) {
+                        dh = pdo[e] + acc[e]; ig = pg[e][0]; fg = pg[e][1]; gg = pg[e][2]; og = pg[e][3]; c = pc[e]; cprev = pcp[e]; dcold = pdc[e];
+                    } else {
+                        dh = ld_any(p.dout, (long long)row * p.do_bs + (long long)td * p.do_ts + d * H + j, p.dout_dtype) + acc[e];
+                        const bf16_t* gs = p.gates + (((long long)td * B + row) * 2 + d) * 4 * H;
+                        ig = (float)gs[j]; fg = (float)gs[H + j]; gg = (float)gs[2 * H + j]; og = (float)gs[3 * H + j];
+                        c = p.cseq[(((long long)td * B + row) * 2 + d) * H + j];
+                        const bool has_prev = d == 0 ? td > 0 : td < T - 1;
+                        cprev = has_prev ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;
+                        dcold = s > 0 ? *dcp : 0.f;
+                    }
+                    const float tc = tanhf(c);
+                    const float dcs = dcold + dh * og * (1.f - tc * tc);
+                    *dcp = dcs * fg;
+                    bf16_t* dg = p.dgates + (((long long)td * B + row) * 2 + d) * 4 * H;
+                    dg[j] = (bf16_t)(dcs * gg * ig * (1.f - ig));
+                    dg[H + j] = (bf16_t)(dcs * cprev * fg * (1.f - fg));
+                    dg[2 * H + j] = (bf16_t)(dcs * ig * (1.f - gg * gg));
+                    dg[3 * H + j] = (bf16_t)(dh * tc * og * (1.f - og));
+                }
+            }
+            __syncthreads();
+        }
+        if (s + 1 < T) publish(cnt, tid);
+    }
+}
+
+constexpr int LDS_F = 64 * WLD * 2 + 64 * ALD * 2;            // 66 560 + 66 560
+constexpr int LDS_B = 16 * WTLD * 2 + 2 * 64 * BLD * 2;         // 65 792 + 67 584
+
+}  // namespace
+
+// counters: 3 ints of workspace (zeroed here); returns after enqueueing; the timeout flag counters[2] can be read later
+extern "C" int av_lstm_fwd_layer(const float* gx, const void* whh, void* hseq, float* cseq, void* gates, void* out_bt, int* counters,
+                                 int T, int B, int Hh, void* stream) {
+    AV_CHECK(gx && whh && hseq && cseq && counters, "av_lstm_fwd_layer: null pointer");
+    AV_CHECK(Hh == H && T > 0 && B > 0, "av_lstm_fwd_layer: persistent kernel is built for H=512 (got %d), T=%d B=%d", Hh, T, B);
+    hipStream_t st = (hipStream_t)stream;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)lstm_fwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F) != hipSuccess ||
+            hipFuncSetAttribute((const void*)lstm_bwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess) {
+            av_set_error("av_lstm_*_layer: cannot raise dynamic LDS"); return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    if (hipMemsetAsync(counters, 0, 3 * sizeof(int), st) != hipSuccess) { av_set_error("av_lstm_fwd_layer: memset failed"); return AV_ERR_LAUNCH; }
+    PF p{gx, (const bf16_t*)whh, (bf16_t*)hseq, cseq, (bf16_t*)gates, (bf16_t*)out_bt, counters, T, B};
+    hipLaunchKernelGGL(lstm_fwd_persistent, dim3(NJT, 2), dim3(256), LDS_F, st, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_lstm_bwd_layer(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgates, const void* whhT,
+                                 const void* gates, const float* cseq, float* dc, int* counters, int T, int B, int Hh, void* stream) {
+    AV_CHECK(dout && dgates && whhT && gates && cseq && dc && counters, "av_lstm_bwd_layer: null pointer");
+    AV_CHECK(Hh == H && T > 0 && B > 0, "av_lstm_bwd_layer: persistent kernel is built for H=512 (got %d), T=%d B=%d", Hh, T, B);
+    hipStream_t st = (hipStream_t)stream;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)lstm_fwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F) != hipSuccess ||
+            hipFuncSetAttribute((const void*)lstm_bwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess) {
+            av_set_error("av_lstm_*_layer: cannot raise dynamic LDS"); return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    if (hipMemsetAsync(counters, 0, 3 * sizeof(int), st) != hipSuccess) { av_set_error("av_lstm_bwd_layer: memset failed"); return AV_ERR_LAUNCH; }
+    PB p{dout, dout_dtype, do_bs, do_ts, (bf16_t*)dgates, (const bf16_t*)whhT, (const bf16_t*)gates, cseq, dc, counters, T, B};
+    hipLaunchKernelGGL(lstm_bwd_persistent, dim3(NJT, 2), dim3(256), LDS_B, st, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+

@@ -18,6 +18,9 @@ from .. import ops
 from ..precision import compute_dtype
 
 Tensor = torch.Tensor
+# one persistent launch per BiLSTM layer (bf16, H = 512) instead of one launch per time step; AVAMD_LSTM_PERSISTENT=0 disables
+import os as _os
+PERSISTENT_LSTM = _os.environ.get("AVAMD_LSTM_PERSISTENT", "1") != "0"
 
 
 class _ParamCache:
@@ -60,10 +63,16 @@ def lstm_forward(mod: "CrossAttentionFusion", x_tm: Tensor, save: bool):
         if last:
             out_bt = torch.empty((B, T, 2 * H), dtype=dtype, device=dev)
         st = ops.stream()
-        fn = L.lib().av_lstm_fwd_step
-        for s in range(T):
-            L.check(fn(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates), ops.ptr(out_bt) if last else None,
-                       ops.dt(hseq), T, B, H, s, st), "av_lstm_fwd_step")
+        if PERSISTENT_LSTM and dtype == torch.bfloat16 and H == 512:
+            cnt = torch.empty(3, dtype=torch.int32, device=dev)
+            L.check(L.lib().av_lstm_fwd_layer(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates),
+                                              ops.ptr(out_bt) if last else None, ops.ptr(cnt), T, B, H, st), "av_lstm_fwd_layer")
+            mod._lstm_flags.append(cnt)
+        else:
+            fn = L.lib().av_lstm_fwd_step
+            for s in range(T):
+                L.check(fn(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates), ops.ptr(out_bt) if last else None,
+                           ops.dt(hseq), T, B, H, s, st), "av_lstm_fwd_step")
         if save:
             layers.append(dict(inp=inp, hseq=hseq, cseq=cseq, gates=gates, wih=wih, whh=whh, names=names))
         inp = hseq
@@ -86,10 +95,16 @@ def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: D
         dgates = torch.empty((T, B, 2, 4 * H), dtype=dtype, device=dev)
         dc = torch.empty((2, B, H), dtype=torch.float32, device=dev)
         st = ops.stream()
-        fn = L.lib().av_lstm_bwd_step
-        for s in range(T):
-            L.check(fn(ops.ptr(dout), ops.dt(dout), do_bs, do_ts, ops.ptr(dgates), ops.ptr(whhT), ops.ptr(gates), ops.ptr(cseq),
-                       ops.ptr(dc), ops.dt(dgates), T, B, H, s, st), "av_lstm_bwd_step")
+        if PERSISTENT_LSTM and dtype == torch.bfloat16 and H == 512:
+            cnt = torch.empty(3, dtype=torch.int32, device=dev)
+            L.check(L.lib().av_lstm_bwd_layer(ops.ptr(dout), ops.dt(dout), do_bs, do_ts, ops.ptr(dgates), ops.ptr(whhT), ops.ptr(gates),
+                                              ops.ptr(cseq), ops.ptr(dc), ops.ptr(cnt), T, B, H, st), "av_lstm_bwd_layer")
+            mod._lstm_flags.append(cnt)
+        else:
+            fn = L.lib().av_lstm_bwd_step
+            for s in range(T):
+                L.check(fn(ops.ptr(dout), ops.dt(dout), do_bs, do_ts, ops.ptr(dgates), ops.ptr(whhT), ops.ptr(gates), ops.ptr(cseq),
+                           ops.ptr(dc), ops.dt(dgates), T, B, H, s, st), "av_lstm_bwd_step")
         M = T * B
         dg2 = dgates.view(M, 8 * H)
         in_f = inp.shape[-1]
@@ -220,6 +235,7 @@ class CrossAttentionFusion(nn.Module):
         self.temporal_model = nn.LSTM(input_size=fused_dim, hidden_size=fused_dim, num_layers=2, batch_first=True, bidirectional=True)
         self.fused_dim, self.num_heads = fused_dim, num_heads
         self._cache = _ParamCache()
+        self._lstm_flags = []          # arrival/timeout words of the persistent LSTM launches (checked lazily)
         if fused_dim % 32 or (fused_dim // num_heads) not in (16, 32, 64, 128):
             raise ValueError("fused_dim must be a multiple of 32 with head_dim in {16,32,64,128} for the HIP kernels")
 
@@ -242,6 +258,10 @@ class CrossAttentionFusion(nn.Module):
         names = [n for n, p in self._np if p.requires_grad]
         params = [p for n, p in self._np if p.requires_grad]
         save = torch.is_grad_enabled() and (bool(names) or audio_feat.requires_grad or visual_feat.requires_grad)
+        if len(self._lstm_flags) > 64:          # lazy check of old launches' timeout words (they are complete by now)
+            old, self._lstm_flags = self._lstm_flags[:32], self._lstm_flags[32:]
+            if int(torch.stack(old)[:, 2].max()) != 0:
+                raise RuntimeError("persistent LSTM kernel: inter-workgroup wait timed out (results of that step are invalid)")
         out, lens, m_out = _FusionFn.apply(self, save, names, groups, visual_feat, audio_feat, mask, *params)
         self.last_mask = m_out
         return out, lens
