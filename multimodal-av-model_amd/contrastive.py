@@ -86,7 +86,7 @@ class _ContrastFn(torch.autograd.Function):
             Pm = f_t[c0:c1]
             # dA += dS P ; dP = dS^T A
             ops.gemm(dsim, Pm, df, M=n1, N=E, K=ncols, lda=ld, ldb=E, ldc=E, b_mode=L.B_KN, R=df, ldr=E)
-            ops.gemm(dsim, f_t, df, M=ncols, N=E, K=n1, lda=ld, ldb=E, ldc=E, a_mode=L.A_TRANS, b_mode=L.B_KN, c_off=c0 * E)
+            ops.matmul_tn(dsim[:, :ncols], f_t[:n1], out=df[c0:c1])          # dP = dS^T A  (transposes + fast GEMM)
         dproj = torch.empty_like(df)
         L.check(L.lib().av_l2norm_bwd(ops.ptr(s["f"]), ops.ptr(df), ops.ptr(s["nrm"]), ops.ptr(dproj), n, E, 1e-12, ops.stream()), "av_l2norm_bwd")
         dproj_t = ops.cast(dproj, dtype)

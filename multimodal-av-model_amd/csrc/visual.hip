@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void bn_prelu_maxpool_vec_kernel(const bf16x8*
 
 inline int vec_grid(long long n8, int C8) {          // blocks of 256 threads; total threads a multiple of C8 (C8 | 256 here)
     long long b = (n8 + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));      // few, long-lived threads: the per-channel parameters are loaded once per thread
 }
 
 inline int ew_grid(long long n) {
