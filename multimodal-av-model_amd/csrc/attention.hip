@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 
     T* Pw = Ps + w * 16 * LDV;
     const T* Qw = Qs + w * 16 * LDK;
+    __syncthreads();                                   // Q tile staged
+    AFrag<T, DK> qf;
+    qf.load(Qw, LDK, lane);                            // my 16 query rows: loaded once, reused for every key tile
     for (int k0 = 0; k0 < klen; k0 += 64) {
         stage_rows<T, D, DK>(Ks, LDK, K, p.k_rs, k0, klen, vec, tid);
         stage_vt<T, D>(Vt, LDV, V, p.v_rs, k0, klen, vec, tid);
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             S[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma_rows<T>(S[j], Qw, LDK, Ks + j * 16 * LDK, LDK, DK, lane);
+            qf.mma(S[j], Ks + j * 16 * LDK, LDK, lane);
         }
         float mx[4];
 #pragma unroll
@@ -103,8 +106,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) O[n][e] *= alpha[e];
         __syncthreads();   // P visible to the whole wave (and keeps the 4 waves in step)
+        {
+            AFrag<T, 64> pf;
+            pf.load(Pw, LDV, lane);
 #pragma unroll
-        for (int n = 0; n < DN; ++n) mma_rows<T>(O[n], Pw, LDV, Vt + n * 16 * LDV, LDV, 64, lane);
+            for (int n = 0; n < DN; ++n) pf.mma(O[n], Vt + n * 16 * LDV, LDV, lane);
+        }
         __syncthreads();   // K / Vt / P tiles are free again
     }
 

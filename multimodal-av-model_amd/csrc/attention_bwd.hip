@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const BwdP p) {
     const T* Kme = Ks + w * 16 * LDK;
     const T* Vme = Vs + w * 16 * LDK;
 
+    __syncthreads();                                                // K / V tiles staged
+    AFrag<T, DK> kf, vf;
+    kf.load(Kme, LDK, lane);                                        // my 16 keys: fragments loaded once for the whole sweep
+    vf.load(Vme, LDK, lane);
     for (int i0 = 0; i0 < p.Tq; i0 += 64) {
         __syncthreads();                                            // previous tile's operands are no longer read
         stage_rows<T, D, DK>(Qs, LDK, Q, p.q_rs, i0, p.Tq, vec, tid);
@@ -109,8 +113,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const BwdP p) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {                               // S^T / dP^T tile: rows = my 16 keys, cols = 16 queries
             f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma_rows<T>(st, Kme, LDK, Qs + n * 16 * LDK, LDK, DK, lane);
-            mma_rows<T>(dpt, Vme, LDK, Os + n * 16 * LDK, LDK, DK, lane);
+            kf.mma(st, Qs + n * 16 * LDK, LDK, lane);
+            vf.mma(dpt, Os + n * 16 * LDK, LDK, lane);
             const int qc = n * 16 + r;
             const bool qok = (i0 + qc) < p.Tq;
             const float l = lse_s[qc], dl = del_s[qc];
@@ -129,10 +133,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const BwdP p) {
             }
         }
         __syncthreads();                                            // P^T / dS^T tiles visible
+        {
+            AFrag<T, 64> pf, sf;
+            pf.load(Pme, LDT, lane);
+            sf.load(Sme, LDT, lane);
 #pragma unroll
-        for (int n = 0; n < DN; ++n) {
-            mma_rows<T>(dVa[n], Pme, LDT, Ot + n * 16 * LDT, LDT, 64, lane);
-            mma_rows<T>(dKa[n], Sme, LDT, Qt + n * 16 * LDT, LDT, 64, lane);
+            for (int n = 0; n < DN; ++n) {
+                pf.mma(dVa[n], Ot + n * 16 * LDT, LDT, lane);
+                sf.mma(dKa[n], Qt + n * 16 * LDT, LDT, lane);
+            }
         }
     }
 #pragma unroll
@@ -190,6 +199,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const BwdP p) {
     const T* Qme = Qs + w * 16 * LDK;
     const T* Ome = Os + w * 16 * LDK;
 
+    __syncthreads();                                                // Q / dO tiles staged
+    AFrag<T, DK> qf, of;
+    qf.load(Qme, LDK, lane);
+    of.load(Ome, LDK, lane);
     for (int j0 = 0; j0 < klen; j0 += 64) {
         __syncthreads();
         stage_rows<T, D, DK>(Ks, LDK, K, p.k_rs, j0, klen, vec, tid);
@@ -199,8 +212,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const BwdP p) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {                               // S / dP tile: rows = my 16 queries, cols = 16 keys
             f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma_rows<T>(st, Qme, LDK, Ks + n * 16 * LDK, LDK, DK, lane);
-            mma_rows<T>(dpt, Ome, LDK, Vs + n * 16 * LDK, LDK, DK, lane);
+            qf.mma(st, Ks + n * 16 * LDK, LDK, lane);
+            of.mma(dpt, Vs + n * 16 * LDK, LDK, lane);
             const bool kok = (j0 + n * 16 + r) < klen;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -214,8 +227,12 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const BwdP p) {
             }
         }
         __syncthreads();
+        {
+            AFrag<T, 64> sf;
+            sf.load(Sme, LDT, lane);
 #pragma unroll
-        for (int n = 0; n < DN; ++n) mma_rows<T>(dQa[n], Sme, LDT, Kt + n * 16 * LDT, LDT, 64, lane);
+            for (int n = 0; n < DN; ++n) sf.mma(dQa[n], Kt + n * 16 * LDT, LDT, lane);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

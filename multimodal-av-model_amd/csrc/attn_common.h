@@ -47,6 +47,42 @@ __device__ __forceinline__ void mma_rows<float>(f32x4& acc, const float* a, int 
     }
 }
 
+// ---- fragment-level helpers: load the A fragments of a 16-row operand ONCE, reuse them against many B tiles ---------
+template <typename T, int K> struct AFrag;
+template <int K> struct AFrag<bf16_t, K> {
+    bf16x8 f[K / 32];
+    __device__ __forceinline__ void load(const bf16_t* a, int lda, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < K / 32; ++i) f[i] = *(const bf16x8*)(a + r * lda + i * 32 + 8 * g);
+    }
+    __device__ __forceinline__ void mma(f32x4& acc, const bf16_t* b, int ldb, int lane) const {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < K / 32; ++i) {
+            const bf16x8 bv = *(const bf16x8*)(b + r * ldb + i * 32 + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[i], bv, acc, 0, 0, 0);
+        }
+    }
+};
+template <int K> struct AFrag<float, K> {
+    f32x4 f[K / 16];
+    __device__ __forceinline__ void load(const float* a, int lda, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < K / 16; ++i) f[i] = *(const f32x4*)(a + r * lda + i * 16 + 4 * g);
+    }
+    __device__ __forceinline__ void mma(f32x4& acc, const float* b, int ldb, int lane) const {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < K / 16; ++i) {
+            const f32x4 bv = *(const f32x4*)(b + r * ldb + i * 16 + 4 * g);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f[i][jj], bv[jj], acc, 0, 0, 0);
+        }
+    }
+};
+
 // stage `rows_tile` x DK elements (zero-filled outside [row_end) x [0,D)) into dst[row][ld]
 template <typename T, int D, int DK>
 __device__ __forceinline__ void stage_rows(T* dst, int ld, const T* src, long long rs, int row0, int row_end, bool vec, int tid) {

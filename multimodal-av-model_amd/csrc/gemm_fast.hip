@@ -433,33 +433,52 @@ __global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm
 
     const int sw = r & 7;
     const int a_off = (wrow + r) * 128, b_off = V2_BM * BK * 2 + (wcol + r) * 128;
+    const int ch0 = ((0 * 4 + g) ^ sw) << 4, ch1 = ((1 * 4 + g) ^ sw) << 4;
+    // fragment double buffering: F0 = k-step 0, F1 = k-step 1 of a K-tile.  Every ds_read group is issued one MFMA
+    // group (16 MFMAs) ahead of its use, the tile hand-over barrier sits between the two MFMA groups.
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+#define LOADF(A_, B_, STG, CH)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) A_[i] = *(const bf16x8*)(smem + (STG) * V2_STAGE + a_off + i * 16 * 128 + (CH)); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) B_[j] = *(const bf16x8*)(smem + (STG) * V2_STAGE + b_off + j * 16 * 128 + (CH));
+#define MMAF(A_, B_)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
+
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // tile 0 landed for everyone
+    LOADF(a0, b0, 0, ch0)
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // my loads of tile kt have landed (tile kt+1 may fly)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                       // tile kt complete for everyone; stage (kt-1)%3 is free
-        if (kt + 2 < nk) {
+    for (int kt = 0; kt + 1 < nk; ++kt) {                                   // all tiles but the last (peeled: no join on the wait state)
+        if (kt + 2 < nk) {                                                  // stage (kt+2)%3 was released by the previous barrier
             int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
             stage(kt + 2, smem + nxt * V2_STAGE);
         }
-        const char* ab = smem + cur * V2_STAGE + a_off;
-        const char* bb = smem + cur * V2_STAGE + b_off;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int choff = ((ks * 4 + g) ^ sw) << 4;
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(ab + i * 16 * 128 + choff);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(bb + j * 16 * 128 + choff);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        cur = cur + 1 == 3 ? 0 : cur + 1;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): F0 (issued one MFMA group ago) is complete
+        LOADF(a1, b1, cur, ch1)                                             // in flight under the MFMAs of F0
+        __builtin_amdgcn_sched_barrier(0);
+        MMAF(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        const int nstage = cur + 1 == 3 ? 0 : cur + 1;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): my reads of tile kt are complete
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // my loads of tile kt+1 landed (tile kt+2 may fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // tile kt+1 complete for everyone; stage cur is free
+        LOADF(a0, b0, nstage, ch0)                                          // in flight under the MFMAs of F1
+        __builtin_amdgcn_sched_barrier(0);
+        MMAF(a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nstage;
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                     // last tile
+    LOADF(a1, b1, cur, ch1)
+    __builtin_amdgcn_sched_barrier(0);
+    MMAF(a0, b0)
+    __builtin_amdgcn_sched_barrier(0);
+    MMAF(a1, b1)
+#undef LOADF
+#undef MMAF
     __syncthreads();                                         // every wave is done reading the last stage
 
     float* cs = (float*)smem;
@@ -538,8 +557,8 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     const long long aes = p.aux_dtype == AV_F32 ? 4 : 2;
     fl.aux_vec = p.aux && al16(p.aux) && (p.ldc * aes) % 16 == 0 && (p.sC * aes) % 16 == 0 && (p.oC * aes) % 16 == 0;
     const bool narrow = p.N <= 64;
-    static const int v2_mode = [] { const char* e = getenv("AVAMD_GEMM_V2"); return e ? atoi(e) : 0; }();   // measured: not faster at M~6k, K=1k
-    if (!conv && !narrow && v2_mode && p.M >= 512) {
+    static const int v2_mode = [] { const char* e = getenv("AVAMD_GEMM_V2"); return e ? atoi(e) : 2; }();   // 0 never, 1 always, 2 (default) when K >= 2048
+    if (!conv && !narrow && p.M >= 512 && (v2_mode == 1 || (v2_mode == 2 && p.K >= 2048))) {
         static bool v2_attr = false;
         if (!v2_attr) {
             if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS) != hipSuccess) {

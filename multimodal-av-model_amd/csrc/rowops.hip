@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const void* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float t = (v[it][e] - mean) * rstd * g[e] + b[e];
-            if (ACT == AV_ACT_GELU) t = gelu_f(t);
+            if (ACT == AV_ACT_GELU) t = ydt == AV_BF16 ? gelu_fast(t) : gelu_f(t);
             o[e] = t;
         }
         st4(y, base + c, ydt, o);
