@@ -241,6 +241,10 @@ extern "C" int av_attention_fwd(const void* q, const void* k, const void* v, voi
         return ((uintptr_t)ptr % 16 == 0) && ((bs * es) % 16 == 0) && ((rs * es) % 16 == 0) && ((D * es) % 16 == 0);
     };
     p.vec_ok = al(q, q_bs, q_rs) && al(k, k_bs, k_rs) && al(v, v_bs, v_rs);
+    if (dtype == AV_BF16) {
+        const int rc = av_attention_short_fwd_try(p, D, (hipStream_t)stream);      // whole-sequence kernel: D = 64, T <= 256
+        if (rc != AV_SHORT_NOT_TAKEN) return rc;
+    }
     return dtype == AV_F32 ? dispatch_d<float>(p, D, (hipStream_t)stream) : dispatch_d<bf16_t>(p, D, (hipStream_t)stream);
 }
 

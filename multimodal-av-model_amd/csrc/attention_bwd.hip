@@ -13,20 +13,6 @@
 
 namespace {
 
-struct BwdP {
-    const bf16_t *q, *k, *v, *dout;
-    const float *lse, *delta;
-    bf16_t *dq, *dk, *dv;
-    const int* klen;
-    int B, H, Tq, Tk;
-    long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
-    float scale;
-    int vec_ok;
-    float drop_p;
-    unsigned drop_stream;
-    unsigned long long drop_seed;
-};
-
 // delta[b][h][t] = sum_d dO o O.  One wavefront per (b, t): the H*D contiguous elements are read with 16-B loads, each lane
 // reduces its 8-element chunks and the lanes of one head are combined with shuffles (chunks per head = D/8, power of 2).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, int B, int H,
@@ -281,6 +267,7 @@ extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, con
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
     p.q_bs = strides[0]; p.q_rs = strides[1]; p.k_bs = strides[2]; p.k_rs = strides[3]; p.v_bs = strides[4]; p.v_rs = strides[5];
     const long long o_bs = strides[6], o_rs = strides[7];
+    p.o = (const bf16_t*)o; p.o_bs = o_bs; p.o_rs = o_rs;
     p.do_bs = strides[8]; p.do_rs = strides[9]; p.dq_bs = strides[10]; p.dq_rs = strides[11]; p.dk_bs = strides[12]; p.dk_rs = strides[13];
     p.dv_bs = strides[14]; p.dv_rs = strides[15];
     p.scale = scale;
@@ -296,6 +283,10 @@ extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, con
              (o_bs * 2) % 16 == 0 && (o_rs * 2) % 16 == 0 && (p.do_bs * 2) % 16 == 0 && (p.do_rs * 2) % 16 == 0,
              "av_attention_bwd: o / dout must be 16-byte aligned views and D/8 a power of two");
     (void)n;
+    {
+        const int rc = av_attention_short_bwd_try(p, D, st);       // whole-sequence kernel (attention_short.hip): D = 64, T <= 256
+        if (rc != AV_SHORT_NOT_TAKEN) return rc;
+    }
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long long)B * Tq + 3) / 4)), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout,
                        delta_ws, B, H, Tq, D, o_bs, o_rs, p.do_bs, p.do_rs);
     AV_LAUNCH_CHECK();

@@ -1,0 +1,382 @@
+// Whole-sequence multi-head attention for SHORT sequences (bf16, head_dim 64, T <= 256): forward and backward of
+// hf:438-463 (wav2vec2 self-attention; T_enc = 49 / 199 for the 1 s / 4 s clips).  At these lengths a flash-style
+// sweep over key tiles is latency-bound (a barrier pair and a global round trip per 64 keys), so here ONE workgroup
+// (8 wavefronts) owns one (batch, head): every operand of the sequence is staged into LDS once, there is a single
+// barrier per phase, and each wavefront walks its 16-row tiles with no further synchronisation.
+//
+//  * products are oriented so that the probability tile is already the next MFMA's B operand: S^T = K Q^T puts the
+//    query on the lane and 4 keys in the accumulator registers, which IS the [k = key][col = query] fragment of
+//    O^T = V^T P^T (two 16-key tiles make one K = 32 step; k-slot (g, j) <-> key 16*(2tp + j/4) + 4g + j%4).  No LDS
+//    round trip for P, no online-softmax rescale: the whole row of scores lives in registers.
+//  * the transposed operand (V^T, and in the backward dO^T, Q^T, K^T) comes from the ROW-major LDS image through
+//    ds_read_b64_tr_b16 (gfx950 transpose read: a 16-lane group reads 4 rows x 16 columns and receives them column-major,
+//    which matches that k-slot map).  One image serves row reads (ds_read_b128) and transposed reads: 128-B rows with
+//    the 16-B chunk XOR-swizzled by (row & 7) are conflict-free for both.
+//  * backward: phase A (LDS = Q, dO; a wavefront owns 16 keys) accumulates dK^T, dV^T from S = Q K^T; phase B
+//    (LDS = K, V; a wavefront owns 16 queries) accumulates dQ^T from S^T = K Q^T.  delta = rowsum(dO o O) is computed while
+//    dO is staged.  No atomics, no cross-workgroup accumulation: bitwise reproducible.
+// Dropout on the probabilities uses the same (seed, stream, index) Philox mask as the tiled kernels.
+#include <stdlib.h>
+
+#include "attn_common.h"
+
+namespace {
+
+constexpr int NW = 8;                          // wavefronts per workgroup
+constexpr int NT = NW * 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+typedef __attribute__((address_space(3))) bf16x4* lds_b4_t;
+
+// element offset of 16-B chunk `ch` (0..7) of row `row` in a [rows][64] bf16 image
+__device__ __forceinline__ int swz(int row, int ch) { return row * 64 + ((ch ^ (row & 7)) << 3); }
+
+__device__ __forceinline__ bf16x8 row_frag(const bf16_t* img, int row, int ch) { return *(const bf16x8*)(img + swz(row, ch)); }
+
+// transposed read of rows r0 + 4g .. r0 + 4g + 3 (g = lane >> 4), columns 16n .. 16n + 15: the lane receives column
+// 16n + (lane & 15), element q = row r0 + 4g + q.  Lane 4q + pp of the group supplies the address of row q, columns 4pp..4pp+3.
+__device__ __forceinline__ bf16x4 tr_read(const bf16_t* img, int r0, int n, int lane) {
+    const int row = r0 + 4 * (lane >> 4) + ((lane >> 2) & 3), pp = lane & 3;
+    const bf16_t* a = img + row * 64 + (((2 * n + (pp >> 1)) ^ (row & 7)) << 3) + 4 * (pp & 1);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)a);
+}
+// A fragment [16 columns of the image][k = 32 rows r0 .. r0+31] in the k-slot order of pack8()
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int r0, int n, int lane) {
+    const bf16x4 lo = tr_read(img, r0, n, lane), hi = tr_read(img, r0 + 16, n, lane);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// B fragment from two accumulator tiles (rows 4g + e of 16-row tiles 2tp and 2tp + 1)
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    bf16x8 v;
+    v[0] = (bf16_t)a[0]; v[1] = (bf16_t)a[1]; v[2] = (bf16_t)a[2]; v[3] = (bf16_t)a[3];
+    v[4] = (bf16_t)b[0]; v[5] = (bf16_t)b[1]; v[6] = (bf16_t)b[2]; v[7] = (bf16_t)b[3];
+    return v;
+}
+__device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// rows [0, nvalid) of src (row stride rs elements, 64 contiguous) -> swizzled image of npad rows, zero-filled beyond nvalid
+__device__ __forceinline__ void stage_img(bf16_t* img, const bf16_t* __restrict__ src, long long rs, int nvalid, int npad, int tid) {
+    for (int c0 = tid; c0 < npad * 8; c0 += 4 * NT) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * NT, row = c >> 3, ch = c & 7;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (row < nvalid) v[u] = *(const uint4*)(src + (long long)row * rs + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * NT, row = c >> 3, ch = c & 7;
+            if (row < npad) *(uint4*)(img + swz(row, ch)) = v[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+template <int NKP, bool DROP>   // 32-key pairs: keys padded to 32 * NKP
+__global__ __launch_bounds__(NT, 4) void attn_fwd_short_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = (bf16_t*)smem;
+    bf16_t* Vs = Ks + NKP * 32 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+    const bf16_t* Q = (const bf16_t*)p.q + (long long)b * p.q_bs + (long long)h * 64;
+    const bf16_t* K = (const bf16_t*)p.k + (long long)b * p.k_bs + (long long)h * 64;
+    const bf16_t* V = (const bf16_t*)p.v + (long long)b * p.v_bs + (long long)h * 64;
+    stage_img(Ks, K, p.k_rs, p.Tk, NKP * 32, tid);
+    stage_img(Vs, V, p.v_rs, p.Tk, NKP * 32, tid);
+    __syncthreads();
+
+    const float c = p.scale * LOG2E;
+    const int nqt = (p.Tq + 15) >> 4;
+    for (int qt = w; qt < nqt; qt += NW) {                      // wave-uniform: EXEC stays all ones for the transposed reads
+        asm volatile("" ::: "memory");                         // keep the (loop-invariant) LDS fragment reads inside the loop: 28 hoisted fragments would spill
+        const int qrow = qt * 16 + r;
+        const bf16_t* qp = Q + (long long)(qrow < p.Tq ? qrow : p.Tq - 1) * p.q_rs + 8 * g;
+        const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+        f32x4 S[2 * NKP];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; ++t) {                    // S^T tile t: rows = keys 16t + 4g + e, column = my query
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            a = mfma(row_frag(Ks, 16 * t + r, g), qf0, a);
+            a = mfma(row_frag(Ks, 16 * t + r, 4 + g), qf1, a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = (16 * t + 4 * g + e) < klen ? a[e] * c : -INFINITY;
+                mx = fmaxf(mx, a[e]);
+            }
+            S[t] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(S[t][e] - mx);
+                sum += pv;
+                S[t][e] = pv;
+            }
+        if (DROP) {
+            const float ik = 1.0f / (1.0f - p.drop_p);
+            const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * p.Tk;
+#pragma unroll
+            for (int t = 0; t < 2 * NKP; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[t][e] *= drop_mult_call(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g + e), p.drop_p, ik);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        f32x4 O[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) O[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < NKP; ++tp) {                     // O^T[d][q] += V^T[d][32 keys] P^T[32 keys][q]
+            const bf16x8 pf = pack8(S[2 * tp], S[2 * tp + 1]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) O[n] = mfma(tr_frag(Vs, 32 * tp, n, lane), pf, O[n]);
+        }
+        if (qrow < p.Tq) {
+            const float inv = 1.0f / sum;
+            bf16_t* o = (bf16_t*)p.o + (long long)b * p.o_bs + (long long)qrow * p.o_rs + (long long)h * 64 + 4 * g;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(O[n][e] * inv);
+                *(bf16x4*)(o + 16 * n) = ov;
+            }
+            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Tq + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- backward
+template <bool DROP>
+__global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int R) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* I0 = (bf16_t*)smem;                 // phase A: Q      phase B: K
+    bf16_t* I1 = I0 + R * 64;                   // phase A: dO     phase B: V
+    float* lse_s = (float*)(I1 + R * 64);       // [R]  log2-domain LSE of each query
+    float* del_s = lse_s + R;                   // [R]  delta = sum_d dO o O
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+    const bf16_t* Q = p.q + (long long)b * p.q_bs + (long long)h * 64;
+    const bf16_t* K = p.k + (long long)b * p.k_bs + (long long)h * 64;
+    const bf16_t* V = p.v + (long long)b * p.v_bs + (long long)h * 64;
+    const bf16_t* O = p.o + (long long)b * p.o_bs + (long long)h * 64;
+    const bf16_t* DO = p.dout + (long long)b * p.do_bs + (long long)h * 64;
+    const float* lse = p.lse + ((long long)b * p.H + h) * p.Tq;
+    const float c = p.scale * LOG2E;
+    const float ik = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const unsigned long long dbase = ((unsigned long long)b * p.H + h) * p.Tq;
+    const int RA = ((p.Tq + 31) >> 5) << 5, RB = ((p.Tk + 31) >> 5) << 5;
+
+    // ---- phase A operands: Q and dO images, delta and LSE per query
+    stage_img(I0, Q, p.q_rs, p.Tq, RA, tid);
+    for (int c0 = tid; c0 < RA * 8; c0 += NT) {                 // 8 consecutive lanes share a row
+        const int row = c0 >> 3, ch = c0 & 7;
+        bf16x8 dv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        float s = 0.f;
+        if (row < p.Tq) {
+            dv = *(const bf16x8*)(DO + (long long)row * p.do_rs + ch * 8);
+            const bf16x8 ov = *(const bf16x8*)(O + (long long)row * p.o_rs + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)dv[e] * (float)ov[e];
+        }
+        *(bf16x8*)(I1 + swz(row, ch)) = dv;
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (ch == 0) del_s[row] = s;
+    }
+    for (int i = tid; i < R; i += NT) lse_s[i] = i < p.Tq ? lse[i] * LOG2E : 0.f;
+    __syncthreads();
+
+    // ---- phase A: a wavefront owns 16 keys; S = Q K^T has the key on the lane, 4 queries in the registers
+    const int nkt = (p.Tk + 15) >> 4, nqp = RA >> 5;
+    for (int kt = w; kt < nkt; kt += NW) {
+        const int krow = kt * 16 + r;
+        const long long kld = krow < p.Tk ? krow : p.Tk - 1;
+        const bf16x8 kf0 = *(const bf16x8*)(K + kld * p.k_rs + 8 * g), kf1 = *(const bf16x8*)(K + kld * p.k_rs + 32 + 8 * g);
+        const bf16x8 vf0 = *(const bf16x8*)(V + kld * p.v_rs + 8 * g), vf1 = *(const bf16x8*)(V + kld * p.v_rs + 32 + 8 * g);
+        const bool kok = krow < klen;
+        f32x4 dVt[4], dKt[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { dVt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int qp = 0; qp < nqp; ++qp) {
+            f32x4 Pt[2], St[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int q0 = 32 * qp + 16 * hf;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                s = mfma(row_frag(I0, q0 + r, g), kf0, s);
+                s = mfma(row_frag(I0, q0 + r, 4 + g), kf1, s);
+                dp = mfma(row_frag(I1, q0 + r, g), vf0, dp);
+                dp = mfma(row_frag(I1, q0 + r, 4 + g), vf1, dp);
+                const f32x4 l4 = *(const f32x4*)(lse_s + q0 + 4 * g), d4 = *(const f32x4*)(del_s + q0 + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = q0 + 4 * g + e;
+                    const float pv = (kok && q < p.Tq) ? __builtin_amdgcn_exp2f(s[e] * c - l4[e]) : 0.f;
+                    float dm = 1.f;
+                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + q) * p.Tk + krow, p.drop_p, ik);
+                    Pt[hf][e] = pv * dm;
+                    St[hf][e] = pv * (dp[e] * dm - d4[e]) * p.scale;
+                }
+            }
+            const bf16x8 pf = pack8(Pt[0], Pt[1]), sf = pack8(St[0], St[1]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                dVt[n] = mfma(tr_frag(I1, 32 * qp, n, lane), pf, dVt[n]);      // dV^T[d][key] += dO^T[d][32 q] P[32 q][key]
+                dKt[n] = mfma(tr_frag(I0, 32 * qp, n, lane), sf, dKt[n]);      // dK^T[d][key] += Q^T[d][32 q] dS[32 q][key]
+            }
+        }
+        if (krow < p.Tk) {
+            bf16_t* ok = p.dk + (long long)b * p.dk_bs + (long long)krow * p.dk_rs + (long long)h * 64 + 4 * g;
+            bf16_t* ov = p.dv + (long long)b * p.dv_bs + (long long)krow * p.dv_rs + (long long)h * 64 + 4 * g;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bf16x4 a, c4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = (bf16_t)dKt[n][e]; c4[e] = (bf16_t)dVt[n][e]; }
+                *(bf16x4*)(ok + 16 * n) = a;
+                *(bf16x4*)(ov + 16 * n) = c4;
+            }
+        }
+    }
+
+    // ---- phase B operands: K and V images replace Q and dO
+    __syncthreads();
+    stage_img(I0, K, p.k_rs, p.Tk, RB, tid);
+    stage_img(I1, V, p.v_rs, p.Tk, RB, tid);
+    __syncthreads();
+
+    // ---- phase B: a wavefront owns 16 queries; S^T = K Q^T has the query on the lane, 4 keys in the registers
+    const int nqt = (p.Tq + 15) >> 4, nkp = RB >> 5;
+    for (int qt = w; qt < nqt; qt += NW) {
+        const int qrow = qt * 16 + r;
+        const long long qld = qrow < p.Tq ? qrow : p.Tq - 1;
+        const bf16x8 qf0 = *(const bf16x8*)(Q + qld * p.q_rs + 8 * g), qf1 = *(const bf16x8*)(Q + qld * p.q_rs + 32 + 8 * g);
+        const bf16x8 of0 = *(const bf16x8*)(DO + qld * p.do_rs + 8 * g), of1 = *(const bf16x8*)(DO + qld * p.do_rs + 32 + 8 * g);
+        const bool qok = qrow < p.Tq;
+        const float lq = lse_s[qrow], dq_ = del_s[qrow];
+        f32x4 dQt[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) dQt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tp = 0; tp < nkp; ++tp) {
+            f32x4 St[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int k0 = 32 * tp + 16 * hf;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                s = mfma(row_frag(I0, k0 + r, g), qf0, s);
+                s = mfma(row_frag(I0, k0 + r, 4 + g), qf1, s);
+                dp = mfma(row_frag(I1, k0 + r, g), of0, dp);
+                dp = mfma(row_frag(I1, k0 + r, 4 + g), of1, dp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + 4 * g + e;
+                    const float pv = (qok && key < klen) ? __builtin_amdgcn_exp2f(s[e] * c - lq) : 0.f;
+                    float dm = 1.f;
+                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + qrow) * p.Tk + key, p.drop_p, ik);
+                    St[hf][e] = pv * (dp[e] * dm - dq_) * p.scale;
+                }
+            }
+            const bf16x8 sf = pack8(St[0], St[1]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) dQt[n] = mfma(tr_frag(I0, 32 * tp, n, lane), sf, dQt[n]);   // dQ^T[d][q] += K^T[d][32 keys] dS^T[32 keys][q]
+        }
+        if (qok) {
+            bf16_t* oq = p.dq + (long long)b * p.dq_bs + (long long)qrow * p.dq_rs + (long long)h * 64 + 4 * g;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bf16x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (bf16_t)dQt[n][e];
+                *(bf16x4*)(oq + 16 * n) = a;
+            }
+        }
+    }
+}
+
+bool short_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AVAMD_ATTN_SHORT");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+
+bool al8(const void* ptr, long long bs, long long rs) { return ((uintptr_t)ptr % 8 == 0) && (bs % 4 == 0) && (rs % 4 == 0); }
+
+template <int NKP, bool DROP>
+int launch_fwd_short2(const AttnP& p, hipStream_t st) {
+    const int lds = 2 * NKP * 32 * 64 * 2;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)attn_fwd_short_kernel<NKP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            av_set_error("av_attention_fwd: cannot raise dynamic LDS to %d", lds);
+            return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_short_kernel<NKP, DROP>), dim3((unsigned)p.H, (unsigned)p.B), dim3(NT), lds, st, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+template <int NKP>
+int launch_fwd_short(const AttnP& p, hipStream_t st) {
+    return p.drop_p > 0.f ? launch_fwd_short2<NKP, true>(p, st) : launch_fwd_short2<NKP, false>(p, st);
+}
+
+template <bool DROP>
+int launch_bwd_short(const BwdP& p, int R, int lds, hipStream_t st) {
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_short_kernel<DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 64 * 2 + 2 * 256 * 4) != hipSuccess) {
+            av_set_error("av_attention_bwd: cannot raise dynamic LDS");
+            return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_short_kernel<DROP>, dim3((unsigned)p.H, (unsigned)p.B), dim3(NT), lds, st, p, R);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+}  // namespace
+
+int av_attention_short_fwd_try(const AttnP& p, int D, hipStream_t st) {
+    if (D != 64 || p.Tk > 256 || p.Tq > 256 || !p.vec_ok || !short_enabled() || !al8(p.o, p.o_bs, p.o_rs) || p.B > 65535) return AV_SHORT_NOT_TAKEN;
+    switch ((p.Tk + 31) / 32) {
+        case 1: return launch_fwd_short<1>(p, st);
+        case 2: return launch_fwd_short<2>(p, st);
+        case 3: return launch_fwd_short<3>(p, st);
+        case 4: return launch_fwd_short<4>(p, st);
+        case 5: return launch_fwd_short<5>(p, st);
+        case 6: return launch_fwd_short<6>(p, st);
+        case 7: return launch_fwd_short<7>(p, st);
+        default: return launch_fwd_short<8>(p, st);
+    }
+}
+
+int av_attention_short_bwd_try(const BwdP& p, int D, hipStream_t st) {
+    if (D != 64 || p.Tk > 256 || p.Tq > 256 || !p.vec_ok || !short_enabled() || p.B > 65535 || !al8(p.dq, p.dq_bs, p.dq_rs) ||
+        !al8(p.dk, p.dk_bs, p.dk_rs) || !al8(p.dv, p.dv_bs, p.dv_rs))
+        return AV_SHORT_NOT_TAKEN;
+    const int tmax = p.Tq > p.Tk ? p.Tq : p.Tk;
+    const int R = (tmax + 31) / 32 * 32;
+    const int lds = 2 * R * 64 * 2 + 2 * R * 4;
+    return p.drop_p > 0.f ? launch_bwd_short<true>(p, R, lds, st) : launch_bwd_short<false>(p, R, lds, st);
+}

@@ -2,12 +2,7 @@
 #pragma once
 #include "av_common.h"
 
-namespace {
-
-template <typename T> struct ACfg;
-template <> struct ACfg<float> { static constexpr int VEC = 4; };
-template <> struct ACfg<bf16_t> { static constexpr int VEC = 8; };
-
+// launch parameter blocks (global scope: shared between attention.hip, attention_bwd.hip and attention_short.hip)
 struct AttnP {
     const void *q, *k, *v;
     void* o;
@@ -21,6 +16,31 @@ struct AttnP {
     unsigned drop_stream;
     unsigned long long drop_seed;
 };
+
+struct BwdP {
+    const bf16_t *q, *k, *v, *o, *dout;
+    const float *lse, *delta;
+    bf16_t *dq, *dk, *dv;
+    const int* klen;
+    int B, H, Tq, Tk;
+    long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    float scale;
+    int vec_ok;
+    float drop_p;
+    unsigned drop_stream;
+    unsigned long long drop_seed;
+};
+
+// whole-sequence kernels for short sequences (attention_short.hip); AV_SHORT_NOT_TAKEN = shape not covered, caller goes on
+#define AV_SHORT_NOT_TAKEN (-1000)
+int av_attention_short_fwd_try(const AttnP& p, int D, hipStream_t st);
+int av_attention_short_bwd_try(const BwdP& p, int D, hipStream_t st);
+
+namespace {
+
+template <typename T> struct ACfg;
+template <> struct ACfg<float> { static constexpr int VEC = 4; };
+template <> struct ACfg<bf16_t> { static constexpr int VEC = 8; };
 
 template <typename T> __device__ __forceinline__ void zero16(T* dst) { *(uint4*)dst = make_uint4(0, 0, 0, 0); }
 

@@ -181,7 +181,10 @@ def test_log_softmax_colsum_cast():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,Tq,Tk,D,masked", [(2, 4, 49, 49, 16, False), (3, 16, 199, 199, 64, True), (2, 4, 100, 100, 128, False),
-                                                (2, 4, 25, 25, 128, False), (1, 2, 300, 300, 64, True), (2, 3, 70, 130, 32, True)])
+                                                (2, 4, 25, 25, 128, False), (1, 2, 300, 300, 64, True), (2, 3, 70, 130, 32, True),
+                                                # D = 64, T <= 256 (bf16): whole-sequence kernels of attention_short.hip
+                                                (2, 4, 49, 49, 64, True), (2, 2, 256, 256, 64, True), (1, 3, 130, 130, 64, False),
+                                                (2, 2, 70, 130, 64, True), (2, 2, 130, 70, 64, True), (1, 1, 1, 1, 64, False)])
 def test_attention_fwd_bwd(dtype, B, H, Tq, Tk, D, masked):
     packed = Tq == Tk
     if packed:
