@@ -188,8 +188,9 @@ int av_contrastive_dsim(const float* s, const float* lse, void* out, int odt, lo
 int av_reduce_sum(const float* x, long long n, float* out, float scale, int accumulate, void* stream);
 int av_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, void* stream);
-/* multi-tensor form (one launch per step): ptrs [n_tensors][4] device pointers {param, grad, exp_avg, exp_avg_sq};
- * chunk c = elements [chunk_start[c], +chunk_elems) of tensor chunk_tensor[c]; all arrays live on the device */
+/* multi-tensor form (one launch per step): ptrs [n_tensors][5] device pointers {param, grad, exp_avg, exp_avg_sq, shadow};
+ * shadow = optional (0 = none) bf16 copy of the updated parameter, same element order (the perf path's cached compute-dtype
+ * weight); chunk c = elements [chunk_start[c], +chunk_elems) of tensor chunk_tensor[c]; all arrays live on the device */
 int av_adam_multi(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
                   int n_chunks, int chunk_elems, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 

@@ -88,29 +88,59 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-// multi-tensor Adam: one launch for every trainable tensor.  ptrs[t] = {param, grad, exp_avg, exp_avg_sq}; chunk c covers
-// elements [chunk_start[c], +chunk_elems) of tensor chunk_tensor[c].
+// multi-tensor Adam: one launch for every trainable tensor.  ptrs[t] = {param, grad, exp_avg, exp_avg_sq, shadow}; chunk c
+// covers elements [chunk_start[c], +chunk_elems) of tensor chunk_tensor[c].  shadow (optional, 0 = none) is a bf16 copy of
+// the parameter in the layout the compute kernels read (the perf path's cached weight): writing it here saves the separate
+// cast pass over every trainable weight after each step.
+__device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+                                          float gscale) {
+    const float gi = g * gscale;
+    m = b1 * m + (1.f - b1) * gi;
+    v = b2 * v + (1.f - b2) * gi * gi;
+    p -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+    return p;
+}
 __global__ __launch_bounds__(256) void adam_multi_kernel(const unsigned long long* __restrict__ ptrs, const long long* __restrict__ sizes,
                                                          const float* __restrict__ lrs, const int* __restrict__ chunk_tensor,
                                                          const long long* __restrict__ chunk_start, int chunk_elems, float b1, float b2,
                                                          float eps, float bc1, float bc2_sqrt, float gscale) {
     const int c = blockIdx.x;
     const int t = chunk_tensor[c];
-    float* p = (float*)ptrs[4 * t + 0];
-    const float* g = (const float*)ptrs[4 * t + 1];
-    float* m = (float*)ptrs[4 * t + 2];
-    float* v = (float*)ptrs[4 * t + 3];
+    float* p = (float*)ptrs[5 * t + 0];
+    const float* g = (const float*)ptrs[5 * t + 1];
+    float* m = (float*)ptrs[5 * t + 2];
+    float* v = (float*)ptrs[5 * t + 3];
+    bf16_t* sh = (bf16_t*)ptrs[5 * t + 4];
     const long long n = sizes[t];
     const long long s0 = chunk_start[c];
     long long s1 = s0 + chunk_elems;
     if (s1 > n) s1 = n;
     const float step_size = lrs[t] / bc1;
-    for (long long i = s0 + threadIdx.x; i < s1; i += 256) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0) && ((uintptr_t)sh % 8 == 0) && (s0 % 4 == 0);
+    long long i = s0;
+    if (vec) {
+        const long long nv = (s1 - s0) / 4;
+        for (long long q = threadIdx.x; q < nv; q += 256) {
+            const long long e = s0 + 4 * q;
+            f32x4 pp = *(const f32x4*)(p + e), mm = *(const f32x4*)(m + e), vv = *(const f32x4*)(v + e);
+            const f32x4 gg = *(const f32x4*)(g + e);
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float pk = pp[k], mk = mm[k], vk = vv[k];
+                o[k] = (bf16_t)adam_one(pk, gg[k], mk, vk, b1, b2, eps, step_size, bc2_sqrt, gscale);
+                pp[k] = pk; mm[k] = mk; vv[k] = vk;
+            }
+            *(f32x4*)(p + e) = pp; *(f32x4*)(m + e) = mm; *(f32x4*)(v + e) = vv;
+            if (sh) *(bf16x4*)(sh + e) = o;
+        }
+        i = s0 + 4 * nv;
+    }
+    for (i += threadIdx.x; i < s1; i += 256) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        const float r = adam_one(pp, g[i], mm, vv, b1, b2, eps, step_size, bc2_sqrt, gscale);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (sh) sh[i] = (bf16_t)r;
     }
 }
 

@@ -303,6 +303,38 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     if (ry == 0 && c < cols) atomicAdd(out + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
 }
 
+// bf16 rows, 16-B loads: a wavefront covers 512 consecutive columns of one row, the 4 wavefronts of a block take rows r0 + w, r0 + w + 4, ...
+constexpr int CSV_ROWS = 128;
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long long rows, int cols, long long ld) {
+    __shared__ float red[3][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 512 + lane * 8;
+    const long long r0 = (long long)blockIdx.y * CSV_ROWS;
+    long long r1 = r0 + CSV_ROWS;
+    if (r1 > rows) r1 = rows;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (c < cols) {
+        const bf16_t* px = x + c;
+#pragma unroll 4
+        for (long long r = r0 + w; r < r1; r += 4) {
+            const bf16x8 v = *(const bf16x8*)(px + r * ld);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w - 1][lane][e] = s[e];
+    }
+    __syncthreads();
+    if (w == 0 && c < cols) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(out + c + e, s[e] + red[0][lane][e] + red[1][lane][e] + red[2][lane][e]);
+    }
+}
+
 __global__ void cast_kernel(const void* __restrict__ x, int xdt, void* __restrict__ y, int ydt, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         st_any(y, i, ydt, ld_any(x, i, xdt));
@@ -447,6 +479,12 @@ extern "C" int av_colsum(const void* x, int xdt, float* out, long long rows, int
         if (hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream) != hipSuccess) { av_set_error("av_colsum: memset failed"); return AV_ERR_LAUNCH; }
     }
     if (rows == 0) return AV_OK;
+    if (xdt == AV_BF16 && cols % 8 == 0 && ld % 8 == 0 && (uintptr_t)x % 16 == 0) {
+        dim3 gv((unsigned)((cols + 511) / 512), (unsigned)((rows + CSV_ROWS - 1) / CSV_ROWS));
+        hipLaunchKernelGGL(colsum_bf16_vec_kernel, gv, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, cols, ld);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + CS_ROWS - 1) / CS_ROWS));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xdt, out, rows, cols, ld);
     AV_LAUNCH_CHECK();

@@ -9,14 +9,14 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..precision import compute_dtype
+from ..utils.shadow import ParamCache
 
 
 class _HeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(fctx, x, w, b):
+    def forward(fctx, x, w, b, wt):
         dtype = compute_dtype()
         xt = ops.cast(x.contiguous().float(), dtype)
-        wt = ops.cast(w.data.contiguous(), dtype)
         logits = ops.linear(xt, wt, b.data, out_dtype=torch.float32)
         lp = ops.log_softmax_fwd(logits)
         fctx.save_for_backward(xt, wt, lp)
@@ -32,7 +32,7 @@ class _HeadFn(torch.autograd.Function):
         dx = ops.matmul_nn(d2, wt, out_dtype=torch.float32).view(xt.shape) if fctx.needs_input_grad[0] else None
         dw = ops.matmul_tn(d2, xt.view(-1, D)) if fctx.needs_input_grad[1] else None
         db = ops.colsum(d2) if fctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class CTCDecoder(nn.Module):
@@ -40,13 +40,16 @@ class CTCDecoder(nn.Module):
         super().__init__()
         self.net = nn.Sequential(nn.Linear(input_dim, vocab_size))     # parameter container: keys net.0.{weight,bias}
         self.ctc_loss = nn.CTCLoss(blank=blank_id, zero_infinity=True)
+        self._cache = ParamCache()
 
     def forward(self, x, target=None, input_lengths=None, target_lengths=None):
         """x [B,T,D] -> log-probs [B,T,V], or the CTC loss when ``target`` is given (model/decoder.py:14-35)."""
         if not x.is_cuda:
             raise RuntimeError("CTCDecoder (HIP): input must be on the GPU; there is no CPU fallback")
         lin = self.net[0]
-        log_probs = _HeadFn.apply(x, lin.weight, lin.bias)
+        dtype = compute_dtype()
+        wt = lin.weight.data if dtype == torch.float32 else self._cache.get("w", [lin.weight], dtype, lambda: ops.cast(lin.weight.data.contiguous(), dtype), flat=True)
+        log_probs = _HeadFn.apply(x, lin.weight, lin.bias, wt)
         if target is not None:
             return self.ctc_loss(log_probs.transpose(0, 1), target, input_lengths, target_lengths)
         return log_probs

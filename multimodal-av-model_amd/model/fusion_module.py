@@ -16,25 +16,12 @@ import torch.nn as nn
 from .. import _lib as L
 from .. import ops
 from ..precision import compute_dtype
+from ..utils.shadow import ParamCache
 
 Tensor = torch.Tensor
 # one persistent launch per BiLSTM layer (bf16, H = 512) instead of one launch per time step; AVAMD_LSTM_PERSISTENT=0 disables
 import os as _os
 PERSISTENT_LSTM = _os.environ.get("AVAMD_LSTM_PERSISTENT", "1") != "0"
-
-
-class _ParamCache:
-    def __init__(self):
-        self.d = {}
-
-    def get(self, key, params, dtype, fn):
-        ver = tuple((p._version, p.data_ptr()) for p in params) + (dtype,)
-        hit = self.d.get(key)
-        if hit is None or hit[0] != ver:
-            with torch.no_grad():
-                hit = (ver, fn())
-            self.d[key] = hit
-        return hit[1]
 
 
 def lstm_forward(mod: "CrossAttentionFusion", x_tm: Tensor, save: bool):
@@ -51,8 +38,8 @@ def lstm_forward(mod: "CrossAttentionFusion", x_tm: Tensor, save: bool):
         names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse", f"weight_hh_l{layer}", f"weight_hh_l{layer}_reverse",
                  f"bias_ih_l{layer}", f"bias_ih_l{layer}_reverse", f"bias_hh_l{layer}", f"bias_hh_l{layer}_reverse"]
         P = [getattr(lstm, n) for n in names]
-        wih = mod._cache.get(("wih", layer), P[0:2], dtype, lambda: ops.cast(torch.cat([P[0].data, P[1].data], 0).contiguous(), dtype))
-        whh = mod._cache.get(("whh", layer), P[2:4], dtype, lambda: ops.cast(torch.stack([P[2].data, P[3].data], 0).contiguous(), dtype))
+        wih = mod._cache.get(("wih", layer), P[0:2], dtype, lambda: ops.cast(torch.cat([P[0].data, P[1].data], 0).contiguous(), dtype), flat=True)
+        whh = mod._cache.get(("whh", layer), P[2:4], dtype, lambda: ops.cast(torch.stack([P[2].data, P[3].data], 0).contiguous(), dtype), flat=True)
         bias = mod._cache.get(("b", layer), P[4:8], torch.float32,
                               lambda: torch.cat([P[4].data + P[6].data, P[5].data + P[7].data], 0).contiguous())
         gx = ops.linear(inp, wih, bias, out_dtype=torch.float32)                         # [T,B,8H] = [T,B,2,4H]
@@ -234,7 +221,7 @@ class CrossAttentionFusion(nn.Module):
         self.fusion_proj = nn.Linear(fused_dim, fused_dim)
         self.temporal_model = nn.LSTM(input_size=fused_dim, hidden_size=fused_dim, num_layers=2, batch_first=True, bidirectional=True)
         self.fused_dim, self.num_heads = fused_dim, num_heads
-        self._cache = _ParamCache()
+        self._cache = ParamCache()
         self._lstm_flags = []          # arrival/timeout words of the persistent LSTM launches (checked lazily)
         if fused_dim % 32 or (fused_dim // num_heads) not in (16, 32, 64, 128):
             raise ValueError("fused_dim must be a multiple of 32 with head_dim in {16,32,64,128} for the HIP kernels")
@@ -242,7 +229,7 @@ class CrossAttentionFusion(nn.Module):
     def cparam(self, p: Tensor, dtype) -> Tensor:
         if dtype == torch.float32:
             return p.data
-        return self._cache.get(("c", id(p)), [p], dtype, lambda: ops.cast(p.data.contiguous(), dtype))
+        return self._cache.get(("c", id(p)), [p], dtype, lambda: ops.cast(p.data.contiguous(), dtype), flat=True)
 
     def forward(self, visual_feat, audio_feat, mask=None, groups: int = 1):
         """visual_feat [B,T_v,D_v], audio_feat [B,T_a,D_a], mask [B,T_a] (0/3 ignore, 1/2 use) ->

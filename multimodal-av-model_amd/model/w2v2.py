@@ -24,6 +24,7 @@ from .. import _lib as L
 from .. import ops
 from ..precision import compute_dtype
 from ..utils import init as _init
+from ..utils.shadow import ParamCache
 
 Tensor = torch.Tensor
 
@@ -110,22 +111,6 @@ def specaugment_mask(batch: int, seq_len: int, mask_prob: float, mask_length: in
     return mask
 
 
-class _Cache:
-    """Compute-dtype copies / re-layouts of parameters, refreshed when the parameter is updated in place."""
-
-    def __init__(self):
-        self.d = {}
-
-    def get(self, key, params: List[Tensor], dtype, fn):
-        ver = tuple((p._version, p.data_ptr()) for p in params) + (dtype,)
-        hit = self.d.get(key)
-        if hit is None or hit[0] != ver:
-            with torch.no_grad():
-                hit = (ver, fn())
-            self.d[key] = hit
-        return hit[1]
-
-
 class Wav2Vec2ModelHIP(nn.Module):
     """Drop-in for the ``transformers.Wav2Vec2Model`` instance the reference stores in ``AudioEncoder.model``."""
 
@@ -134,7 +119,7 @@ class Wav2Vec2ModelHIP(nn.Module):
         self.cfg = dict(cfg)
         self.config = SimpleNamespace(**cfg, output_hidden_states=True)
         build_param_tree(self, param_shapes(cfg))
-        self._cache = _Cache()
+        self._cache = ParamCache()
         self._names = [n for n, _ in self.named_parameters()]
         # data-parallel hooks (parallel/dp.py): per-layer gradient bucket -> async all-reduce, joined at the end of backward
         self.grad_ready = None
@@ -156,11 +141,11 @@ class Wav2Vec2ModelHIP(nn.Module):
         p = self.P(name)
         if dtype == torch.float32:
             return p.data
-        return self._cache.get(("c", name), [p], dtype, lambda: ops.cast(p.data, dtype))
+        return self._cache.get(("c", name), [p], dtype, lambda: ops.cast(p.data, dtype), flat=True)
 
     def qkv_w(self, li: int, dtype):
         ps = [self.P(f"encoder.layers.{li}.attention.{n}_proj.weight") for n in ("q", "k", "v")]
-        return self._cache.get(("qkvw", li), ps, dtype, lambda: ops.cast(torch.cat([p.data for p in ps], 0).contiguous(), dtype))
+        return self._cache.get(("qkvw", li), ps, dtype, lambda: ops.cast(torch.cat([p.data for p in ps], 0).contiguous(), dtype), flat=True)
 
     def qkv_b(self, li: int):
         ps = [self.P(f"encoder.layers.{li}.attention.{n}_proj.bias") for n in ("q", "k", "v")]

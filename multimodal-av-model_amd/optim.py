@@ -8,6 +8,7 @@ import torch
 
 from . import _lib as L
 from . import ops
+from .utils import shadow
 
 
 class AvAdam(torch.optim.Optimizer):
@@ -59,14 +60,18 @@ class AvAdam(torch.optim.Optimizer):
             return self._step_per_tensor(plist, loss)
         sizes, lrs, ct, cs, nch = self._plan(plist)
         grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p, _, _ in plist]
-        flat = []
+        flat, shadowed = [], []
         for (p, _, st), g in zip(plist, grads):
-            flat += [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()]
+            sh = shadow.lookup(p)                               # bf16 compute copy of this parameter (perf path), written by the kernel
+            if sh is not None:
+                shadowed.append(p)
+            flat += [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), sh.data_ptr() if sh is not None else 0]
         ptrs = torch.tensor(flat, dtype=torch.long).to(plist[0][0].device, non_blocking=True)
         L.check(L.lib().av_adam_multi(ops.ptr(ptrs), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK, float(b1),
                                       float(b2), eps, steps.pop(), float(self.grad_scale), ops.stream()), "av_adam_multi")
         self._keep = (ptrs, grads)                              # alive until the next step (stream-ordered use)
-        torch.autograd.graph.increment_version([p for p, _, _ in plist])     # refresh compute-dtype weight caches
+        torch.autograd.graph.increment_version([p for p, _, _ in plist])     # other compute-dtype caches (re-layouts) rebuild
+        shadow.mark_fresh(shadowed)                                          # ... the shadows were just written
         return loss
 
     def _step_per_tensor(self, plist, loss):

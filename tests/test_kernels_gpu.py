@@ -171,6 +171,9 @@ def test_log_softmax_colsum_cast():
     torch.testing.assert_close(ops.log_softmax_bwd(y, dy, torch.float32), xr.grad, rtol=1e-5, atol=1e-5)
     big = _rand(1300, 200)
     torch.testing.assert_close(ops.colsum(big), big.sum(0), rtol=1e-4, atol=1e-4)
+    for rows, cols in ((1300, 200), (6368, 1024), (5, 8), (777, 4096)):           # bf16: 16-byte-load kernel (cols % 8 == 0)
+        hb = _rand(rows, cols, dtype=torch.bfloat16)
+        torch.testing.assert_close(ops.colsum(hb), hb.float().sum(0), rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(ops.cast(big, torch.bfloat16), big.to(torch.bfloat16), rtol=0, atol=0)
     z = _rand(1300, 200)
     torch.testing.assert_close(ops.axpby(2.0, big, 0.5, z.clone()), 2 * big + 0.5 * z)

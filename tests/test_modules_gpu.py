@@ -204,3 +204,43 @@ def test_avadam_multi_tensor_matches_torch():
     for r, m in zip(ref, mine):
         torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-6, atol=1e-7)
     assert set(o_mine.state[mine[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_avadam_writes_bf16_shadows_and_keeps_caches_coherent():
+    """The fused step writes the bf16 compute copies of the parameters it updates (utils/shadow.py): after a step the cached
+    copy equals a fresh cast of the master weights and is NOT rebuilt; an out-of-band update invalidates it."""
+    optim, shadow = pkg("optim"), pkg("utils.shadow")
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(300, 64, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(100, 64, generator=g).cuda().requires_grad_(True)
+    c = torch.randn(77, generator=g).cuda().requires_grad_(True)                     # odd size: scalar tail of the kernel
+    cache = shadow.ParamCache()
+    builds = []
+
+    def cat_ab():
+        builds.append("ab")
+        return torch.cat([a.data, b.data], 0).to(torch.bfloat16)
+
+    def cast_c():
+        builds.append("c")
+        return c.data.to(torch.bfloat16)
+
+    ab0 = cache.get("ab", [a, b], torch.bfloat16, cat_ab, flat=True)
+    c0 = cache.get("c", [c], torch.bfloat16, cast_c, flat=True)
+    opt = optim.AvAdam([a, b, c], lr=1e-2)
+    for step in range(3):
+        for p in (a, c):                                                             # b never has a gradient: its slice stays valid
+            p.grad = torch.randn(p.shape, generator=g).cuda()
+        opt.step()
+        ab = cache.get("ab", [a, b], torch.bfloat16, cat_ab, flat=True)
+        cc = cache.get("c", [c], torch.bfloat16, cast_c, flat=True)
+        assert ab.data_ptr() == ab0.data_ptr() and cc.data_ptr() == c0.data_ptr()    # same storage, updated in place
+        torch.testing.assert_close(ab, torch.cat([a.data, b.data], 0).to(torch.bfloat16), rtol=0, atol=0)
+        torch.testing.assert_close(cc, c.data.to(torch.bfloat16), rtol=0, atol=0)
+    assert builds == ["ab", "c"]                                                     # never rebuilt by the optimizer steps
+    with torch.no_grad():
+        a.mul_(2.0)                                                                  # out-of-band update: version bump -> rebuild
+    assert shadow.lookup(a) is None
+    ab = cache.get("ab", [a, b], torch.bfloat16, cat_ab, flat=True)
+    torch.testing.assert_close(ab, torch.cat([a.data, b.data], 0).to(torch.bfloat16), rtol=0, atol=0)
+    assert builds == ["ab", "c", "ab"]
