@@ -73,8 +73,15 @@ typedef struct av_gemm_args {
     float drop_p;
     unsigned int drop_stream;
     unsigned long long drop_seed;
+    /* optional split-K over the (one-level) batch: when k_total > 0, batch z multiplies k in [z*K, min((z+1)*K, k_total)).
+     * Only with both operands k-major (a_mode 1, b_mode 1, bf16 fast kernel): dW = dY^T X with few output tiles; the
+     * partial products C + z*sC are summed with av_sum_slices. */
+    int k_total;
 } av_gemm_args;
 int av_gemm(const av_gemm_args* args, void* stream);
+/* out[i] = (accumulate ? out[i] : 0) + alpha * sum_s parts[s*stride + i], i < n (fp32): the split-K partials of av_gemm */
+int av_sum_slices(const float* parts, int n_slices, long long n, long long stride, float alpha, float* out, int accumulate,
+                  void* stream);
 /* out[C][Rpad] = in[R][C]^T (zero-filled for r >= R): brings dX / dW products to the fast K-contiguous form */
 int av_transpose(const void* in, int idt, void* out, int odt, int R, int C, long long ldi, int Rpad, void* stream);
 

@@ -31,6 +31,7 @@ class GemmArgs(C.Structure):
         ("cOh", i32), ("cOw", i32),
         ("batch_inner", i32), ("oA", ll), ("oB", ll), ("oC", ll),
         ("drop_p", f32), ("drop_stream", C.c_uint), ("drop_seed", C.c_ulonglong),
+        ("k_total", i32),
     ]
 
 
@@ -40,6 +41,7 @@ SIGNATURES = {
     "av_version": [],
     "av_gemm": [C.POINTER(GemmArgs), vp],
     "av_transpose": [vp, i32, vp, i32, i32, i32, ll, i32, vp],
+    "av_sum_slices": [vp, i32, ll, ll, f32, vp, i32, vp],
     "av_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, ll, i32, f32, i32, vp],
     "av_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp],
     "av_log_softmax_fwd": [vp, i32, vp, ll, i32, vp],

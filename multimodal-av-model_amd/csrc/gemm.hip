@@ -399,6 +399,7 @@ extern "C" int av_gemm(const av_gemm_args* a, void* stream) {
         const int fr = av_gemm_fast_try(p, st);
         if (fr >= 0) return fr;
     }
+    AV_CHECK(p.k_total == 0, "av_gemm: split-K (k_total) needs the bf16 fast path with both operands k-major (a_mode 1, b_mode 1, M, N multiples of 8 and > 64)");
     const bool wide = p.N > 64;
     if (p.in_dtype == AV_F32) {
         const bool av = vec_ok2<float>(p.A, p.lda, p.sA, p.oA), bv = vec_ok2<float>(p.B, p.ldb, p.sB, p.oB);

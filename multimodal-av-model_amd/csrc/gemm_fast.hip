@@ -42,6 +42,47 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, long
     }
 }
 
+
+// ---- k-major operands (element (k, c) at base[k * ld + c]: the A of dW = dY^T X, the B of dX = dY W) --------------------
+// Tile = 64 k-rows x 128 columns (256-B rows), filled by LDS-DMA (a wave instruction = 4 rows); MFMA fragments come out of it
+// with ds_read_b64_tr_b16: a 16-lane group reads 4 k-rows x 16 columns and receives them column-major, so lane (c = lane & 15,
+// g = lane >> 4) gets k = 8g .. 8g+7 of its column from two reads (rows 8g + 0..3 and 8g + 4..7) - the natural k order of the
+// 16x16x32 operand, i.e. compatible with a row-major partner read with ds_read_b128.  The 16-B chunk of a row is XOR-swizzled
+// with s(row) = ((row & 3) << 2) | ((row >> 2) & 3) (applied to the DMA source), which makes those reads bank-conflict free.
+typedef __attribute__((address_space(3))) bf16x4* lds_b4_t;
+
+__device__ __forceinline__ void stage_kmajor(const bf16_t* __restrict__ base, long long ld, int col0, int ncols, int k0, int K, char* tile,
+                                             int w, int lane) {
+    const int rsub = lane >> 4, pos = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (w * 4 + i) * 4 + rsub;
+        const int sx = ((row & 3) << 2) | ((row >> 2) & 3);
+        const int col = col0 + ((pos ^ sx) << 3), k = k0 + row;
+        const bf16_t* src = (k < K && col < ncols) ? base + (long long)k * ld + col : (const bf16_t*)g_zero_line;
+        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 4 + i) * 1024));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+    }
+}
+
+// per-lane byte offsets (inside a k-major tile, k-step 0) of the two transposed reads of column tile `ct`
+struct KmOff { int lo, hi; };
+__device__ __forceinline__ KmOff kmajor_off(int ct, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int r1 = 8 * g + q, r2 = r1 + 4;
+    const int s1 = ((r1 & 3) << 2) | ((r1 >> 2) & 3), s2 = ((r2 & 3) << 2) | ((r2 >> 2) & 3);
+    const int ch = 2 * ct + (pp >> 1);
+    KmOff o;
+    o.lo = r1 * 256 + ((ch ^ s1) << 4) + 8 * (pp & 1);
+    o.hi = r2 * 256 + ((ch ^ s2) << 4) + 8 * (pp & 1);
+    return o;
+}
+__device__ __forceinline__ bf16x8 kmajor_frag(const char* tile, const KmOff& o, int ks) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(tile + ks * 32 * 256 + o.lo));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(tile + ks * 32 * 256 + o.hi));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 struct ConvRows { long long pix[4]; int iy0[4], ix0[4]; };
 
 __device__ __forceinline__ void conv_rows_init(ConvRows& cr, const av_gemm_args& p, int m0, int w, int lane) {
@@ -159,7 +200,8 @@ __device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const Fast
 
 // BNT = 128: waves 2(M) x 2(N), 64 x 64 each.   BNT = 64: waves 4(M) x 1(N), 32 x 64 each (N <= 64 problems:
 // ResNet layer1, grouped positional conv).   CONV: A operand is the implicit im2col of an NHWC image.
-template <int BNT, bool CONV>
+// AKM / BKM: that operand is k-major (A stored [K][M], B stored [K][N]); BNT = 128, no CONV.
+template <int BNT, bool CONV, bool AKM = false, bool BKM = false>
 __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
     constexpr int WM_T = BNT == 128 ? 4 : 2;                 // m-tiles per wave
     constexpr int TILE_BB = BNT * BK * 2;                    // B tile bytes
@@ -195,6 +237,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
 
     ConvRows cr;
     if constexpr (CONV) conv_rows_init(cr, p, m0, w, lane);
+    int Kz = p.K;                                            // split-K: this batch's slice of k_total (the last one may be shorter)
+    if constexpr (AKM && BKM) {
+        if (p.k_total > 0 && p.k_total - z * p.K < Kz) Kz = p.k_total - z * p.K;
+    }
 
     f32x4 acc[WM_T][4];
 #pragma unroll
@@ -204,11 +250,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
 
     auto stage = [&](int kt, char* buf) {
         if constexpr (CONV) stage_conv(A, p, cr, kt * BK, buf, w, lane);
+        else if constexpr (AKM) stage_kmajor(A, p.lda, m0, p.M, kt * BK, Kz, buf, w, lane);
         else stage_rows<4>(A, p.lda, m0, p.M, kt * BK, buf, w, lane);
-        stage_rows<BNT / 32>(B, p.ldb, n0, p.N, kt * BK, buf + TILE_A, w, lane);
+        if constexpr (BKM) stage_kmajor(B, p.ldb, n0, p.N, kt * BK, Kz, buf + TILE_A, w, lane);
+        else stage_rows<BNT / 32>(B, p.ldb, n0, p.N, kt * BK, buf + TILE_A, w, lane);
     };
 
-    const int nk = p.K / BK;
+    const int nk = (Kz + BK - 1) / BK;                       // a ragged last K-step only with k-major operands (rows >= K are zero lines)
+    KmOff ao[WM_T], bo[4];
+    if constexpr (AKM) {
+#pragma unroll
+        for (int i = 0; i < WM_T; ++i) ao[i] = kmajor_off(wrow / 16 + i, lane);
+    }
+    if constexpr (BKM) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bo[j] = kmajor_off(wcol / 16 + j, lane);
+    }
     stage(0, smem);
     __syncthreads();
 
@@ -226,9 +283,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
             const int choff = ((ks * 4 + g) ^ sw) << 4;
             bf16x8 a[WM_T], b[4];
 #pragma unroll
-            for (int i = 0; i < WM_T; ++i) a[i] = *(const bf16x8*)(ab + i * 16 * 128 + choff);
+            for (int i = 0; i < WM_T; ++i) {
+                if constexpr (AKM) a[i] = kmajor_frag(smem + cur * STAGE, ao[i], ks);
+                else a[i] = *(const bf16x8*)(ab + i * 16 * 128 + choff);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(bb + j * 16 * 128 + choff);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (BKM) b[j] = kmajor_frag(smem + cur * STAGE + TILE_A, bo[j], ks);
+                else b[j] = *(const bf16x8*)(bb + j * 16 * 128 + choff);
+            }
 #pragma unroll
             for (int i = 0; i < WM_T; ++i)
 #pragma unroll
@@ -517,12 +580,12 @@ __global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm
     }
 }
 
-template <int BNT, bool CONV>
+template <int BNT, bool CONV, bool AKM = false, bool BKM = false>
 int launch_fast(const av_gemm_args& p, hipStream_t st, const FastFlags& fl) {
     constexpr int STAGE = TILE_A + BNT * BK * 2;
     constexpr int EPI = BM * (BNT + 4) * 4;
     constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-    auto kern = gemm_nt_bf16_kernel<BNT, CONV>;
+    auto kern = gemm_nt_bf16_kernel<BNT, CONV, AKM, BKM>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -540,10 +603,16 @@ int launch_fast(const av_gemm_args& p, hipStream_t st, const FastFlags& fl) {
 
 // returns -1 when the arguments do not qualify for the fast path
 int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
-    if (p.in_dtype != AV_BF16 || p.b_mode != AV_B_NK) return -1;
+    if (p.in_dtype != AV_BF16) return -1;
+    if (p.k_total > 0 && !(p.a_mode == AV_A_TRANS && p.b_mode == AV_B_KN && p.batch_inner == 0 && (long long)(p.batch - 1) * p.K < p.k_total)) return -1;
     const bool conv = p.a_mode == AV_A_CONV2D;
-    if (!conv && p.a_mode != AV_A_ROWMAJOR) return -1;
-    if (p.K < BK || p.K % BK || p.ldb % 8 || p.sA % 8 || p.sB % 8 || p.oA % 8 || p.oB % 8) return -1;
+    const bool akm = p.a_mode == AV_A_TRANS, bkm = p.b_mode == AV_B_KN;        // k-major operands: A [K][M], B [K][N]
+    if (!conv && !akm && p.a_mode != AV_A_ROWMAJOR) return -1;
+    if (!bkm && p.b_mode != AV_B_NK) return -1;
+    if (p.K < BK || p.ldb % 8 || p.sA % 8 || p.sB % 8 || p.oA % 8 || p.oB % 8) return -1;
+    if (p.K % BK && !(akm && bkm)) return -1;                                   // a row-major operand needs whole 64-wide K-steps
+    if (conv && bkm) return -1;
+    if ((akm && (p.M % 8 || p.M <= 64)) || (bkm && (p.N % 8 || p.N <= 64))) return -1;
     if (!al16(p.A) || !al16(p.B) || p.M < 1 || p.N < 1) return -1;
     if (conv) {
         if (p.cCin % 64 || p.cCtot % 8 || p.cCoff % 8) return -1;
@@ -557,6 +626,12 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     const long long aes = p.aux_dtype == AV_F32 ? 4 : 2;
     fl.aux_vec = p.aux && al16(p.aux) && (p.ldc * aes) % 16 == 0 && (p.sC * aes) % 16 == 0 && (p.oC * aes) % 16 == 0;
     const bool narrow = p.N <= 64;
+    if (akm || bkm) {
+        if (p.stats || p.lda % 8) return -1;
+        if (akm && bkm) return launch_fast<128, false, true, true>(p, st, fl);
+        if (akm) return launch_fast<128, false, true, false>(p, st, fl);
+        return launch_fast<128, false, false, true>(p, st, fl);
+    }
     static const int v2_mode = [] { const char* e = getenv("AVAMD_GEMM_V2"); return e ? atoi(e) : 2; }();   // 0 never, 1 always, 2 (default) when K >= 2048
     if (!conv && !narrow && p.M >= 512 && (v2_mode == 1 || (v2_mode == 2 && p.K >= 2048))) {
         static bool v2_attr = false;

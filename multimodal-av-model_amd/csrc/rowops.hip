@@ -335,6 +335,52 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
     }
 }
 
+// fp32 rows, 16-B loads: a wavefront covers 256 consecutive columns of one row
+__global__ __launch_bounds__(256) void colsum_f32_vec_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows, int cols, long long ld) {
+    __shared__ float red[3][64][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const long long r0 = (long long)blockIdx.y * CSV_ROWS;
+    long long r1 = r0 + CSV_ROWS;
+    if (r1 > rows) r1 = rows;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        const float* px = x + c;
+#pragma unroll 4
+        for (long long r = r0 + w; r < r1; r += 4) s += *(const f32x4*)(px + r * ld);
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[w - 1][lane][e] = s[e];
+    }
+    __syncthreads();
+    if (w == 0 && c < cols) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, s[e] + red[0][lane][e] + red[1][lane][e] + red[2][lane][e]);
+    }
+}
+
+__global__ void sum_slices_kernel(const float* __restrict__ parts, int S, long long n, long long stride, float alpha, float* __restrict__ out,
+                                  int accumulate, int vec) {
+    if (vec) {
+        const long long n4 = n / 4;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+            f32x4 s = *(const f32x4*)(parts + 4 * i);
+            for (int k = 1; k < S; ++k) s += *(const f32x4*)(parts + (long long)k * stride + 4 * i);     // fixed order: reproducible
+            s *= alpha;
+            if (accumulate) s += *(const f32x4*)(out + 4 * i);
+            *(f32x4*)(out + 4 * i) = s;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            float s = parts[i];
+            for (int k = 1; k < S; ++k) s += parts[(long long)k * stride + i];
+            s *= alpha;
+            out[i] = accumulate ? out[i] + s : s;
+        }
+    }
+}
+
 __global__ void cast_kernel(const void* __restrict__ x, int xdt, void* __restrict__ y, int ydt, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         st_any(y, i, ydt, ld_any(x, i, xdt));
@@ -485,8 +531,25 @@ extern "C" int av_colsum(const void* x, int xdt, float* out, long long rows, int
         AV_LAUNCH_CHECK();
         return AV_OK;
     }
+    if (xdt == AV_F32 && cols % 4 == 0 && ld % 4 == 0 && (uintptr_t)x % 16 == 0) {
+        dim3 gv((unsigned)((cols + 255) / 256), (unsigned)((rows + CSV_ROWS - 1) / CSV_ROWS));
+        hipLaunchKernelGGL(colsum_f32_vec_kernel, gv, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, rows, cols, ld);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + CS_ROWS - 1) / CS_ROWS));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xdt, out, rows, cols, ld);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_sum_slices(const float* parts, int n_slices, long long n, long long stride, float alpha, float* out, int accumulate,
+                             void* stream) {
+    AV_CHECK(parts && out && n_slices >= 1 && n >= 0 && stride >= n, "av_sum_slices: bad args (slices=%d n=%lld stride=%lld)", n_slices, n, stride);
+    if (n == 0) return AV_OK;
+    const int vec = n % 4 == 0 && stride % 4 == 0 && (uintptr_t)parts % 16 == 0 && (uintptr_t)out % 16 == 0;
+    hipLaunchKernelGGL(sum_slices_kernel, dim3(ew_grid(vec ? n / 4 : n)), dim3(256), 0, (hipStream_t)stream, parts, n_slices, n, stride, alpha, out,
+                       accumulate, vec);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

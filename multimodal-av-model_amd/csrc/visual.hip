@@ -10,13 +10,14 @@
 
 namespace {
 
+constexpr int BNR_ROWS = 64;     // rows of partials per workgroup: nblk / 64 workgroups keep the short reduction off a single-wave tail
 // stage 1: column sums of the [nblk][2C] partial matrix in double (coalesced over channels, f64 atomics to ws[2C])
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ part, int nblk, int C2, double* __restrict__ ws) {
     __shared__ double red[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
-    const int r0 = blockIdx.y * 512;
-    int r1 = r0 + 512;
+    const int r0 = blockIdx.y * BNR_ROWS;
+    int r1 = r0 + BNR_ROWS;
     if (r1 > nblk) r1 = nblk;
     double s = 0.0;
     if (c < C2)
@@ -204,7 +205,7 @@ extern "C" int av_bn_finalize(const float* partial, int nblk, long long count, c
     hipStream_t st = (hipStream_t)stream;
     if (training) {
         if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { av_set_error("av_bn_finalize: memset failed"); return AV_ERR_LAUNCH; }
-        hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * C + 63) / 64, (nblk + 511) / 512), dim3(256), 0, st, partial, nblk, 2 * C, ws);
+        hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * C + 63) / 64, (nblk + BNR_ROWS - 1) / BNR_ROWS), dim3(256), 0, st, partial, nblk, 2 * C, ws);
         AV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ws, (double)count, gamma, beta,

@@ -5,6 +5,7 @@ PyTorch provides device memory and streams; every arithmetic op on the path is a
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -59,7 +60,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
          R: Optional[Tensor] = None, ldr: int = 0, aux: Optional[Tensor] = None, C2: Optional[Tensor] = None,
          stats: Optional[Tensor] = None, alpha: float = 1.0, batch: int = 1, sA: int = 0, sB: int = 0, sC: int = 0,
          sR: int = 0, sBias: int = 0, conv: Optional[dict] = None, a_off: int = 0, b_off: int = 0, c_off: int = 0,
-         batch_inner: int = 0, oA: int = 0, oB: int = 0, oC: int = 0, drop: Optional[tuple] = None) -> Tensor:
+         batch_inner: int = 0, oA: int = 0, oB: int = 0, oC: int = 0, drop: Optional[tuple] = None, k_total: int = 0) -> Tensor:
     """Raw av_gemm call.  Offsets are in elements."""
     _req(A, "gemm A"); _req(B, "gemm B"); _req(C_, "gemm C")
     if A.dtype != B.dtype:
@@ -75,6 +76,7 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
     a.lda, a.ldb, a.ldc, a.ldr = lda, ldb, ldc, (ldr or ldc)
     a.sA, a.sB, a.sC, a.sR, a.sBias = sA, sB, sC, sR, sBias
     a.batch_inner, a.oA, a.oB, a.oC = batch_inner, oA, oB, oC
+    a.k_total = k_total
     if drop is not None and drop[0] > 0:
         a.drop_p, a.drop_seed, a.drop_stream = float(drop[0]), int(drop[1]), int(drop[2])     # (p, seed, stream id)
     a.a_mode, a.b_mode = a_mode, b_mode
@@ -148,6 +150,10 @@ def _fast_ok(t: Tensor, K: int, N: int) -> bool:
     return t.dtype == torch.bfloat16 and K >= 64 and N > 64
 
 
+# k-major operands straight into the fast GEMM (transposed LDS reads) instead of a transpose pass; AVAMD_GEMM_KMAJOR=0 = old path
+KMAJOR = os.environ.get("AVAMD_GEMM_KMAJOR", "1") != "0"
+
+
 def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, act: int = L.ACT_NONE,
               aux: Optional[Tensor] = None, R: Optional[Tensor] = None, out: Optional[Tensor] = None, alpha: float = 1.0,
               b_is_weight: bool = False, drop: Optional[tuple] = None) -> Tensor:
@@ -158,12 +164,27 @@ def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, 
     assert b.shape[0] == K and a.is_contiguous() and b.is_contiguous()
     if out is None:
         out = torch.empty(a.shape[:-1] + (N,), dtype=out_dtype or a.dtype, device=a.device)
-    if _fast_ok(a, K, N) and K % 64 == 0:
+    if _fast_ok(a, K, N) and K % 64 == 0 and (b_is_weight or not (KMAJOR and N % 8 == 0)):
         bt = transpose_cached(b) if b_is_weight else transpose(b)   # [N, K]: K-contiguous operand for the fast kernel
         gemm(a, bt, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act, aux=aux, R=R, alpha=alpha, drop=drop)
         return out
+    # bf16, K % 64 == 0, N % 8 == 0, b not a (cached) weight: the fast kernel reads the k-major B through transposed LDS reads
     gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_mode=L.B_KN, act=act, aux=aux, R=R, alpha=alpha, drop=drop)
     return out
+
+
+def _split_k(tiles: int, Kk: int, mn: int, slots: int = 512) -> int:
+    """Number of K slices for dW-shaped products: minimise rounds(tiles * S over 2 workgroups per CU) * K / S plus the
+    partial-sum traffic (S fp32 slices written and read once)."""
+    best, best_cost = 1, None
+    for S in range(1, 9):
+        if S > 1 and Kk // S < 512:
+            break
+        rounds = (tiles * S + slots - 1) // slots
+        cost = rounds * (Kk / S) * 22e-9 + (S * mn * 8 / 5e12 if S > 1 else 0.0)
+        if best_cost is None or cost < best_cost * 0.97:
+            best, best_cost = S, cost
+    return best
 
 
 def matmul_tn(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, alpha: float = 1.0, accumulate: bool = False) -> Tensor:
@@ -174,11 +195,23 @@ def matmul_tn(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, alpha: floa
     assert b.shape[0] == Kk and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    if _fast_ok(a, Kk, N) and M > 64:
+    if _fast_ok(a, Kk, N) and M > 64 and not (KMAJOR and M % 8 == 0 and N % 8 == 0 and N > 64 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0):
         at = transpose(a, pad_to=64)             # [M, Kp]  token dimension becomes the contiguous K (zero padded)
         bt = transpose(b, pad_to=64)             # [N, Kp]
         Kp = at.shape[1]
         gemm(at, bt, out, M=M, N=N, K=Kp, lda=Kp, ldb=Kp, ldc=N, alpha=alpha, R=out if accumulate else None)
+        return out
+    km = KMAJOR and _fast_ok(a, Kk, N) and M > 64 and M % 8 == 0 and N % 8 == 0 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    S = _split_k(tiles, Kk, M * N) if km else 1      # few output tiles, long K (tokens): split K over the batch dimension
+    if S > 1:
+        chunk = ((Kk + S - 1) // S + 63) // 64 * 64
+        S = (Kk + chunk - 1) // chunk
+    if S > 1:
+        parts = torch.empty((S, M, N), dtype=torch.float32, device=a.device)
+        gemm(a, b, parts, M=M, N=N, K=chunk, lda=a.stride(0), ldb=b.stride(0), ldc=N, a_mode=L.A_TRANS, b_mode=L.B_KN, batch=S,
+             sA=chunk * a.stride(0), sB=chunk * b.stride(0), sC=M * N, k_total=Kk)
+        L.check(L.lib().av_sum_slices(ptr(parts), S, M * N, M * N, float(alpha), ptr(out), int(accumulate), stream()), "av_sum_slices")
         return out
     gemm(a, b, out, M=M, N=N, K=Kk, lda=a.stride(0), ldb=b.stride(0), ldc=N, a_mode=L.A_TRANS, b_mode=L.B_KN, alpha=alpha,
          R=out if accumulate else None)

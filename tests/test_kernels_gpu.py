@@ -171,6 +171,8 @@ def test_log_softmax_colsum_cast():
     torch.testing.assert_close(ops.log_softmax_bwd(y, dy, torch.float32), xr.grad, rtol=1e-5, atol=1e-5)
     big = _rand(1300, 200)
     torch.testing.assert_close(ops.colsum(big), big.sum(0), rtol=1e-4, atol=1e-4)
+    odd = _rand(1300, 203)                                                          # cols % 4 != 0: scalar kernel
+    torch.testing.assert_close(ops.colsum(odd), odd.sum(0), rtol=1e-4, atol=1e-4)
     for rows, cols in ((1300, 200), (6368, 1024), (5, 8), (777, 4096)):           # bf16: 16-byte-load kernel (cols % 8 == 0)
         hb = _rand(rows, cols, dtype=torch.bfloat16)
         torch.testing.assert_close(ops.colsum(hb), hb.float().sum(0), rtol=1e-3, atol=1e-3)
@@ -283,3 +285,27 @@ def test_conv3d_front_fast_kernel():
     torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(stats[:, 0].sum(0), ref.sum(0), rtol=2e-3, atol=0.5)
     torch.testing.assert_close(stats[:, 1].sum(0), (ref * ref).sum(0), rtol=2e-3, atol=0.5)
+
+
+@pytest.mark.parametrize("Kk,M,N", [(100, 136, 200), (64, 128, 128), (777, 264, 72), (6368, 1024, 1024), (199, 4096, 1024)])
+def test_fast_gemm_kmajor_operands(Kk, M, N):
+    """k-major operands read through ds_read_b64_tr_b16 (dW = dY^T X with both operands [tokens][features], dX = dY W with
+    W [out][in]): ragged K, ragged tiles, row-strided views, and an exact integer check that would expose a transposed tile."""
+    dt_ = torch.bfloat16
+    at = _rand(Kk, M, dtype=dt_, scale=1 / math.sqrt(Kk)); b = _rand(Kk, N, dtype=dt_)
+    torch.testing.assert_close(ops.matmul_tn(at, b), _ref_mm(at.t(), b), rtol=2e-2, atol=3e-2)
+    wide = _rand(Kk, 3 * M, dtype=dt_, scale=1 / math.sqrt(Kk))                     # row-strided view (a q/k/v slice of a packed tensor)
+    torch.testing.assert_close(ops.matmul_tn(wide[:, M:2 * M], b), _ref_mm(wide[:, M:2 * M].t(), b), rtol=2e-2, atol=3e-2)
+    # exact: small integers, asymmetric operands
+    ai = (torch.arange(Kk * M, device="cuda").reshape(Kk, M) % 7 - 3).to(dt_)
+    bi = (torch.arange(Kk * N, device="cuda").reshape(Kk, N) % 5 - 2).to(dt_)
+    torch.testing.assert_close(ops.matmul_tn(ai, bi), (ai.float().t() @ bi.float()), rtol=0, atol=0)
+    acc = _rand(M, N)                                                                 # alpha / accumulate (through av_sum_slices when K is split)
+    ref = acc + 0.5 * (ai.float().t() @ bi.float())
+    ops.matmul_tn(ai, bi, out=acc, alpha=0.5, accumulate=True)
+    torch.testing.assert_close(acc, ref, rtol=1e-5, atol=1e-3)
+    if True:
+        K2 = (Kk + 63) // 64 * 64                                                     # dX form: A row-major [M2, K2], B k-major [K2, N]
+        a2 = (torch.arange(300 * K2, device="cuda").reshape(300, K2) % 7 - 3).to(dt_)
+        b2 = (torch.arange(K2 * N, device="cuda").reshape(K2, N) % 5 - 2).to(dt_)
+        torch.testing.assert_close(ops.matmul_nn(a2, b2, out_dtype=torch.float32), a2.float() @ b2.float(), rtol=0, atol=0)
