@@ -138,8 +138,7 @@ def main():
     T_v = cpu_batch["lip1"].shape[1]
     T_enc = int(imp("model.w2v2").conv_out_lengths(cfg, T_audio))
     batch = {k: v.to(dev) for k, v in cpu_batch.items()}
-    batch["_counts1"] = t._class_counts(cpu_batch["mask1"], T_enc)
-    batch["_counts2"] = t._class_counts(cpu_batch["mask2"], T_enc)
+    batch.update(t.host_metadata(cpu_batch, T_enc))        # class counts + CTC lengths from the host copy: no device read-back in the step
 
     def barrier():
         if world > 1:

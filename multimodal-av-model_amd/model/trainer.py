@@ -96,15 +96,48 @@ class MultimodalTrainer:
         return out
 
     @staticmethod
-    def _class_counts(mask_cpu: torch.Tensor, T_enc: int):
-        """(#1, #2, #0) of the down-sampled mask, computed on the host copy of the batch (no device sync when the
-        batch arrives from a DataLoader; a device-resident batch should carry precomputed ``_counts1/_counts2``)."""
+    def _mask_ds_host(mask_cpu: torch.Tensor, T_enc: int) -> torch.Tensor:
+        """Host restatement of av_mask_downsample (nearest index floor(i * Tin / T_enc), fp32 as on the device)."""
         mask_cpu = mask_cpu.cpu()
         Tin = mask_cpu.shape[1]
         scale = torch.tensor(Tin / T_enc, dtype=torch.float32)
         idx = torch.floor(torch.arange(T_enc, dtype=torch.float32) * scale).long().clamp_(max=Tin - 1)
-        c = torch.bincount(mask_cpu[:, idx].reshape(-1).clamp(0, 3), minlength=4).tolist()
+        return mask_cpu[:, idx]
+
+    @staticmethod
+    def _class_counts(mask_cpu: torch.Tensor, T_enc: int):
+        """(#1, #2, #0) of the down-sampled mask, computed on the host copy of the batch (no device sync when the
+        batch arrives from a DataLoader; a device-resident batch should carry precomputed ``_counts1/_counts2``)."""
+        c = torch.bincount(MultimodalTrainer._mask_ds_host(mask_cpu, T_enc).reshape(-1).clamp(0, 3), minlength=4).tolist()
         return (c[1], c[2], c[0])
+
+    @staticmethod
+    def _fusion_lengths_host(mask_cpu: torch.Tensor, T_enc: int, Tv: int) -> torch.Tensor:
+        """Host restatement of the ``input_lengths`` CrossAttentionFusion returns for ONE call (model/fusion_module.py:41-59 of the
+        reference; av_fusion_gather_lerp_fwd here): n_b speech frames (mask 1/2) are kept per item and padded to the call's
+        maximum Tm, the mask is resampled to Tv frames with nearest index floor(i * Tm / Tv), and the length is the number
+        of resampled positions that fall on a kept frame."""
+        import numpy as np
+        m = MultimodalTrainer._mask_ds_host(mask_cpu, T_enc)
+        n = ((m == 1) | (m == 2)).sum(1).numpy().astype(np.int64)
+        Tm = int(n.max()) if n.size else 0
+        i = np.arange(Tv, dtype=np.float32)
+        if Tm == Tv:
+            j = np.arange(Tv, dtype=np.int64)
+        else:
+            j = np.floor(i * (np.float32(Tm) / np.float32(Tv))).astype(np.int64)
+            j = np.minimum(j, max(Tm - 1, 0))
+        return torch.from_numpy((j[None, :] < n[:, None]).sum(1).astype(np.int64))
+
+    def host_metadata(self, cpu_batch: Dict[str, torch.Tensor], T_enc: int) -> Dict[str, object]:
+        """Everything the step would otherwise read back from the device, computed from the HOST copy of a collated batch:
+        contrastive class counts and the CTC length vectors (nn.functional.ctc_loss wants its lengths on the host; handing
+        it device tensors costs a full device synchronisation per call).  Keys start with ``_``; merge into the batch."""
+        Tv = cpu_batch["lip1"].shape[1]
+        il = torch.cat([self._fusion_lengths_host(cpu_batch["mask1"], T_enc, Tv), self._fusion_lengths_host(cpu_batch["mask2"], T_enc, Tv)])
+        tl = torch.cat([cpu_batch["text1_lengths"].cpu().long(), cpu_batch["text2_lengths"].cpu().long()])
+        return {"_counts1": self._class_counts(cpu_batch["mask1"], T_enc), "_counts2": self._class_counts(cpu_batch["mask2"], T_enc),
+                "_ctc_input_lengths": il, "_ctc_target_lengths": tl}
 
     def forward_losses(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """model/trainer.py:66-119 for one batch; everything stays on the device."""
@@ -168,7 +201,9 @@ class MultimodalTrainer:
             Lm = max(t1.shape[1], t2.shape[1])
             tg = torch.cat([F.pad(t1, (0, Lm - t1.shape[1])), F.pad(t2, (0, Lm - t2.shape[1]))], 0)
             tl = torch.cat([d["text1_lengths"], d["text2_lengths"]], 0)
-            nll = F.ctc_loss(lp12.transpose(0, 1), tg, il12, tl, blank=self.tokenizer.blank_id, reduction="none", zero_infinity=True)
+            il_h, tl_h = batch.get("_ctc_input_lengths"), batch.get("_ctc_target_lengths")     # host copies: no device sync in ctc_loss
+            nll = F.ctc_loss(lp12.transpose(0, 1), tg, il12 if il_h is None else il_h, tl if tl_h is None else tl_h,
+                             blank=self.tokenizer.blank_id, reduction="none", zero_infinity=True)
             per = nll / tl.clamp_min(1).to(nll.dtype)
             l1, l2 = per[:B].mean(), per[B:].mean()
         else:

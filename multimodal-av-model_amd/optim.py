@@ -60,18 +60,28 @@ class AvAdam(torch.optim.Optimizer):
             return self._step_per_tensor(plist, loss)
         sizes, lrs, ct, cs, nch = self._plan(plist)
         grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p, _, _ in plist]
-        flat, shadowed = [], []
-        for (p, _, st), g in zip(plist, grads):
-            sh = shadow.lookup(p)                               # bf16 compute copy of this parameter (perf path), written by the kernel
-            if sh is not None:
-                shadowed.append(p)
+        shadows = shadow.lookup_many([p for p, _, _ in plist])  # bf16 compute copies (perf path), written by the kernel
+        flat = []
+        for (p, _, st), g, sh in zip(plist, grads, shadows):
             flat += [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), sh.data_ptr() if sh is not None else 0]
-        ptrs = torch.tensor(flat, dtype=torch.long).to(plist[0][0].device, non_blocking=True)
-        L.check(L.lib().av_adam_multi(ops.ptr(ptrs), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK, float(b1),
+        if getattr(self, "_ptr_list", None) != flat:            # the caching allocator usually hands the gradients the same blocks
+            dev = plist[0][0].device
+            if getattr(self, "_ptr_host", None) is None or self._ptr_host.numel() != len(flat):
+                self._ptr_host = torch.empty(len(flat), dtype=torch.long).pin_memory()
+                self._ptr_dev = torch.empty(len(flat), dtype=torch.long, device=dev)
+                self._ptr_evt = None
+            if self._ptr_evt is not None:
+                self._ptr_evt.synchronize()                     # the previous upload has left the pinned buffer
+            self._ptr_host.copy_(torch.tensor(flat, dtype=torch.long))
+            self._ptr_dev.copy_(self._ptr_host, non_blocking=True)
+            self._ptr_evt = torch.cuda.Event(); self._ptr_evt.record()
+            self._ptr_list = flat
+        L.check(L.lib().av_adam_multi(ops.ptr(self._ptr_dev), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK, float(b1),
                                       float(b2), eps, steps.pop(), float(self.grad_scale), ops.stream()), "av_adam_multi")
-        self._keep = (ptrs, grads)                              # alive until the next step (stream-ordered use)
-        torch.autograd.graph.increment_version([p for p, _, _ in plist])     # other compute-dtype caches (re-layouts) rebuild
-        shadow.mark_fresh(shadowed)                                          # ... the shadows were just written
+        self._keep = grads                                      # alive until the next step (stream-ordered use)
+        params = [p for p, _, _ in plist]
+        torch.autograd.graph.increment_version(params)          # other compute-dtype caches (re-layouts) rebuild
+        shadow.mark_fresh([p for p, sh in zip(params, shadows) if sh is not None])      # ... the shadows were just written
         return loss
 
     def _step_per_tensor(self, plist, loss):

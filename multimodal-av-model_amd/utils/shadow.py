@@ -67,6 +67,22 @@ def lookup(p: Tensor) -> Optional[Tensor]:
     return hit[1] if hit[2].current() else None
 
 
+def lookup_many(params: Sequence[Tensor]) -> List[Optional[Tensor]]:
+    """``lookup`` for a list of parameters, validating every cache entry once."""
+    ok, out = {}, []
+    for p in params:
+        hit = _SHADOW.get(id(p))
+        if hit is None or hit[0]() is not p:
+            out.append(None)
+            continue
+        e = hit[2]
+        good = ok.get(id(e))
+        if good is None:
+            good = ok[id(e)] = e.current()
+        out.append(hit[1] if good else None)
+    return out
+
+
 def mark_fresh(params: Sequence[Tensor]):
     """After the optimizer wrote the shadows of ``params`` (and bumped their versions): the entries are up to date."""
     seen = set()

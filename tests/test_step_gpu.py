@@ -128,3 +128,23 @@ def test_step_bf16_reported_error():
     e_loss = abs(float(out["total"]) - float(fx["train_total"]))
     print(f"bf16 step: max|dlogp| = {e_lp:.4f}, |dloss| = {e_loss:.4f} (loss {float(fx['train_total']):.3f})")
     assert e_lp < 0.5 and e_loss < 0.5
+
+
+def test_host_metadata_gives_the_same_step():
+    """A device-resident batch that carries host_metadata() (CTC lengths / class counts from the host copy: no device read-back
+    inside the step) must produce exactly the losses of the plain batch, and the host lengths must equal the device ones."""
+    init = pkg("utils.init"); synth = pkg("dataset.synthetic"); w2 = pkg("model.w2v2")
+    cfg = init.W2V2_TINY
+    t = build(cfg, "fp32")
+    cpu_batch = synth.make_batch(3, 1.0, seed=77, ragged=True)
+    T_enc = int(w2.conv_out_lengths(cfg, cpu_batch["audio"].shape[1]))
+    dev_batch = {k: v.cuda() for k, v in cpu_batch.items()}
+    t.visual_encoder.train(); t.audio_encoder.train(); t.fusion_module.train(); t.decoder1.train()
+    with torch.no_grad():
+        plain = t.forward_losses(dict(dev_batch))
+        md = t.host_metadata(cpu_batch, T_enc)
+        fast = t.forward_losses({**dev_batch, **md})
+    il = torch.cat([plain["input_lengths1"], plain["input_lengths2"]]).cpu()
+    assert torch.equal(il, md["_ctc_input_lengths"])
+    for k in ("loss1", "loss2", "contrast1", "contrast2", "total"):
+        assert float(plain[k]) == float(fast[k]), k
