@@ -192,12 +192,14 @@ def main():
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")       # separate rocprofv3 --pmc passes (see file)
             if args.precision == "bf16" and os.path.exists(pmc):
+                tb = tl = 0                                                     # launch-weighted over the two tilings of the family
                 for kname, kv in json.load(open(pmc))["kernels"].items():
-                    if kname.startswith("void gemm_nt_bf16_kernel<128, false>"):
-                        traffic = kv["fetch_bytes_per_launch"] + kv["write_bytes_per_launch"]
+                    if "gemm_nt_bf16_kernel<128, false, false, false>" in kname or "gemm_nt_bf16_v2_kernel" in kname:
+                        tb += kv["launches"] * (kv["fetch_bytes_per_launch"] + kv["write_bytes_per_launch"]); tl += kv["launches"]
+                traffic = round(tb / tl) if tl else None
             n = len(probe["records"])
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_kernel<128,false>" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>") + " (all nn.Linear-form products: forward, dX, dW, strided conv1d)",
+            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_kernel<128,false,false,false> + gemm_nt_bf16_v2_kernel (K >= 2048)" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>") + " (all nn.Linear-form products: forward, dX, dW, strided conv1d)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_note": "HBM-side bytes per launch from profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
                     "algorithmic_bytes_per_launch": round(tot_by / n),

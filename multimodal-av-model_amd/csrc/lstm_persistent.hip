@@ -52,6 +52,22 @@ __device__ __forceinline__ void wait_for(int* counter, int target, int* flag, in
     __syncthreads();
 }
 
+// bf16 perf path: v_exp_f32 / v_rcp_f32 forms (relative error ~1e-6, far below the bf16 the gates are stored in)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __expf(-2.f * fabsf(x));
+    return copysignf((1.f - e) * __frcp_rn(1.f + e), x);
+}
+__device__ __forceinline__ void store_rest(const PF& p, int td, int row, int d, int j, float c, float h, float ig, float fg, float gg, float og) {
+    const int B = p.B, T = p.T;
+    p.cseq[(((long long)td * B + row) * 2 + d) * H + j] = c;
+    if (p.out_bt) p.out_bt[((long long)row * T + td) * 2 * H + d * H + j] = (bf16_t)h;
+    if (p.gates) {
+        bf16_t* go = p.gates + (((long long)td * B + row) * 2 + d) * 4 * H;
+        go[j] = (bf16_t)ig; go[H + j] = (bf16_t)fg; go[2 * H + j] = (bf16_t)gg; go[3 * H + j] = (bf16_t)og;
+    }
+}
+
 constexpr int ALD = H + 8;                  // forward A tile row (64 rows x 520 bf16)
 constexpr int BCH = 256, BLD = BCH + 8;     // backward A chunk: 64 rows x 256 of K = 4H, double buffered
 
@@ -72,6 +88,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
     __syncthreads();
     int* cnt = p.counters + d;
     const int j = j0 + r;
+    const bool defer = B <= 64;
     for (int s = 0; s < T; ++s) {
         const int td = d == 0 ? s : T - 1 - s;
         const int tp = d == 0 ? td - 1 : td + 1;
@@ -88,6 +105,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
             pcp[e] = (ok && s > 0) ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;        // my own earlier store
         }
         if (s > 0) wait_for(cnt, NJT * s, p.counters + 2, tid);      // every tile of my direction finished step s-1
+        float sv[4][6];                                              // B <= 64 (one row group): values of the deferred stores
         for (int mbase = 0; mbase < B; mbase += 64) {
             f32x4 acc[4];
 #pragma unroll
@@ -130,24 +148,27 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
                         for (int q = 0; q < 4; ++q) gxv[q] = gxr[q * H + j];
                         cprev = s > 0 ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;
                     }
-                    const float ig = sigmoid_f(acc[0][e] + gxv[0]);
-                    const float fg = sigmoid_f(acc[1][e] + gxv[1]);
-                    const float gg = tanhf(acc[2][e] + gxv[2]);
-                    const float og = sigmoid_f(acc[3][e] + gxv[3]);
+                    const float ig = sigmoid_fast(acc[0][e] + gxv[0]);
+                    const float fg = sigmoid_fast(acc[1][e] + gxv[1]);
+                    const float gg = tanh_fast(acc[2][e] + gxv[2]);
+                    const float og = sigmoid_fast(acc[3][e] + gxv[3]);
                     const float c = fg * cprev + ig * gg;
-                    const float h = og * tanhf(c);
-                    p.cseq[(((long long)td * B + row) * 2 + d) * H + j] = c;
-                    p.hseq[((long long)td * B + row) * 2 * H + d * H + j] = (bf16_t)h;
-                    if (p.out_bt) p.out_bt[((long long)row * T + td) * 2 * H + d * H + j] = (bf16_t)h;
-                    if (p.gates) {
-                        bf16_t* go = p.gates + (((long long)td * B + row) * 2 + d) * 4 * H;
-                        go[j] = (bf16_t)ig; go[H + j] = (bf16_t)fg; go[2 * H + j] = (bf16_t)gg; go[3 * H + j] = (bf16_t)og;
-                    }
+                    const float h = og * tanh_fast(c);
+                    p.hseq[((long long)td * B + row) * 2 * H + d * H + j] = (bf16_t)h;      // the only store other workgroups wait for
+                    if (defer) { sv[e][0] = c; sv[e][1] = h; sv[e][2] = ig; sv[e][3] = fg; sv[e][4] = gg; sv[e][5] = og; }
+                    else store_rest(p, td, row, d, j, c, h, ig, fg, gg, og);
                 }
             }
             __syncthreads();                                         // Al is rewritten by the next row group / step
         }
         if (s + 1 < T) publish(cnt, tid);
+        if (defer) {                                                 // c, gates, out_bt: behind the hand-off, under the next step's wait
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = w * 16 + 4 * g + e;
+                if (row < B) store_rest(p, td, row, d, j, sv[e][0], sv[e][1], sv[e][2], sv[e][3], sv[e][4], sv[e][5]);
+            }
+        }
     }
 }
 
@@ -247,7 +268,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
                         cprev = has_prev ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;
                         dcold = s > 0 ? *dcp : 0.f;
                     }
-                    const float tc = tanhf(c);
+                    const float tc = tanh_fast(c);
                     const float dcs = dcold + dh * og * (1.f - tc * tc);
                     *dcp = dcs * fg;
                     bf16_t* dg = p.dgates + (((long long)td * B + row) * 2 + d) * 4 * H;
