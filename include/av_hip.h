@@ -176,6 +176,10 @@ int av_scatter_rows(const float* src, const long long* idx, float* out, long lon
  * w bf16 [64][288] with k = (kt*7+ky)*8+kx (kx padded to 8, K padded to 288), y bf16 [B*T][H/2][W/2][64],
  * stats [B*T*(H/16)*(W/32)][2][64] BatchNorm partials (optional). */
 int av_conv3d_front(const float* x, const void* w, void* y, float* stats, int B, int T, int H, int W, void* stream);
+/* bf16 fast path of the 3x3 / stride 1 / pad 1, 64 -> 64 channel convolutions of ResNet-18 layer1 (model/encoder.py:44-57):
+ * x bf16 NHWC [n_img][H][W][64], w bf16 [64][9*64] with k = (ky*3+kx)*64 + c, y bf16 [n_img*H*W][64],
+ * stats [ceil(n_img*H*W/256)][2][64] BatchNorm partials (optional).  Weights stay in LDS, the input is staged once per filter row. */
+int av_conv3x3_c64(const void* x, const void* w, void* y, float* stats, int n_img, int H, int W, void* stream);
 int av_bn_finalize(const float* partial, int nblk, long long count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
                    float* shift, int C, double* ws /* 2C doubles */, void* stream);

@@ -62,6 +62,9 @@ from ..precision import compute_dtype  # noqa: E402
 _TRUNK = ((64, 1), (128, 2), (256, 2), (512, 2))      # (planes, stride of the first block) for layer1..4
 
 
+FAST_C64 = os.environ.get("AVAMD_CONV_C64", "1") != "0"        # 0: layer1 through the implicit-GEMM kernel (A/B runs)
+
+
 class BasicBlock(nn.Module):
     """Container for one residual block: conv3x3-BN-PReLU-conv3x3-BN (+1x1 conv-BN shortcut) -> add -> PReLU.
     A single PReLU (``relu``) serves both activations, as in the reference (model/encoder.py:11,18,22)."""
@@ -156,6 +159,13 @@ class VisualEncoder(nn.Module):
         Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
         M = N * Ho * Wo
         y = torch.empty((M, Cout), dtype=dtype, device=x.device)
+        if dtype == torch.bfloat16 and (k, st, pad, Cin, Cout) == (3, 1, 1, 64, 64) and W <= 31 and M < (1 << 24) and FAST_C64:
+            # layer1: weights-stationary kernel (conv3x3_c64.hip), one BN partial per 256 output pixels
+            nblk = (M + 255) // 256
+            stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device) if training else None
+            L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(self._w(conv, dtype)), ops.ptr(y), ops.ptr(stats), N, H, W, ops.stream()),
+                    "av_conv3x3_c64")
+            return y, stats, nblk, M, Ho, Wo
         nblk = (M + 127) // 128
         stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device) if training else None
         geo = dict(cT=1, cH=H, cW=W, cCtot=Cin, cCin=Cin, cCoff=0, cKt=1, cKh=k, cKw=k, cSh=st, cSw=st, cPt=0, cPh=pad, cPw=pad,

@@ -309,3 +309,29 @@ def test_fast_gemm_kmajor_operands(Kk, M, N):
         a2 = (torch.arange(300 * K2, device="cuda").reshape(300, K2) % 7 - 3).to(dt_)
         b2 = (torch.arange(K2 * N, device="cuda").reshape(K2, N) % 5 - 2).to(dt_)
         torch.testing.assert_close(ops.matmul_nn(a2, b2, out_dtype=torch.float32), a2.float() @ b2.float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("n_img,H,W", [(5, 24, 24), (3, 10, 7), (1, 3, 3), (40, 24, 24)])
+def test_conv3x3_c64_weights_stationary(n_img, H, W):
+    """conv3x3_c64.hip (ResNet layer1 shape: 3x3, stride 1, pad 1, 64 -> 64, NHWC bf16) against torch conv2d in fp64 on the same
+    bf16 operands, with the BatchNorm partial sums; sizes cover ragged last tiles, images smaller than a window and many tiles
+    per workgroup."""
+    x = _rand(n_img, H, W, 64, dtype=torch.bfloat16)
+    w = _rand(64, 64, 3, 3, dtype=torch.bfloat16, scale=1 / 24.0)
+    wk = w.permute(0, 2, 3, 1).reshape(64, 576).contiguous()                          # [Cout][(ky*3+kx)*64 + c]
+    M = n_img * H * W
+    y = torch.empty(M, 64, device="cuda", dtype=torch.bfloat16)
+    nblk = (M + 255) // 256
+    stats = torch.empty(nblk, 2, 64, device="cuda")
+    L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(wk), ops.ptr(y), ops.ptr(stats), n_img, H, W, ops.stream()), "av_conv3x3_c64")
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(M, 64)
+    torch.testing.assert_close(y.double(), ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(stats[:, 0].sum(0).double(), ref.sum(0), rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(stats[:, 1].sum(0).double(), (ref * ref).sum(0), rtol=1e-3, atol=2e-2)
+    # exact: small integers (any mis-addressed tap or seam would show)
+    xi = (torch.arange(M * 64, device="cuda").reshape(n_img, H, W, 64) % 5 - 2).to(torch.bfloat16)
+    wi = (torch.arange(64 * 576, device="cuda").reshape(64, 64, 3, 3) % 3 - 1).to(torch.bfloat16)
+    wki = wi.permute(0, 2, 3, 1).reshape(64, 576).contiguous()
+    L.check(L.lib().av_conv3x3_c64(ops.ptr(xi), ops.ptr(wki), ops.ptr(y), None, n_img, H, W, ops.stream()), "av_conv3x3_c64")
+    refi = torch.nn.functional.conv2d(xi.double().permute(0, 3, 1, 2), wi.double(), padding=1).permute(0, 2, 3, 1).reshape(M, 64)
+    torch.testing.assert_close(y.double(), refi.to(torch.bfloat16).double(), rtol=0, atol=0)
