@@ -322,6 +322,31 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = (bias && gnt + e < p.N) ? bias[gnt + e] : 0.f;
     }
+    // Fast tails: a store whose data registers are reused by the next iteration's LDS reads makes the compiler drain vmcnt(0)
+    // in between, i.e. one store round trip per iteration.  For the common epilogues all rows are therefore produced first
+    // (distinct registers) and stored together.
+    if (n0 + BNT <= p.N && fl.c_vec && !p.C2 && p.act == AV_ACT_NONE && p.drop_p <= 0.f && !R && !p.stats && p.out_dtype == AV_BF16) {
+        constexpr int NIT = BM * CPR / NT;
+        uint4 ov[NIT];
+        const int cc = (tid % CPR) * 8;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = (it * NT + tid) / CPR;
+            const f32x4 v0 = *(const f32x4*)(cs + row * CLD + cc), v1 = *(const f32x4*)(cs + row * CLD + cc + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)(v0[e] + bv[e]); o[4 + e] = (bf16_t)(v1[e] + bv[4 + e]); }
+            ov[it] = __builtin_bit_cast(uint4, o);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" :: "v"(ov[it].x), "v"(ov[it].y), "v"(ov[it].z), "v"(ov[it].w));
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = (it * NT + tid) / CPR;
+            if (m0 + row < p.M) *(uint4*)((bf16_t*)p.C + cbase + (long long)(m0 + row) * p.ldc + n0 + cc) = ov[it];
+        }
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < BM * CPR / NT; ++it) {
         const int id = it * NT + tid;
