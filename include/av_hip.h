@@ -197,6 +197,10 @@ int av_lse_rows(const float* s, float* lse, float* rowsum, long long rows, int c
 int av_contrastive_dsim(const float* s, const float* lse, void* out, int odt, long long rows, int cols, int ld, float coef,
                         void* stream);
 int av_reduce_sum(const float* x, long long n, float* out, float scale, int accumulate, void* stream);
+/* greedy CTC decoding (beam_search.py:2-48; the reference's beam search returns the per-frame argmax path): log_probs fp32
+ * [B][T][V], lengths optional int64 [B] (frames to decode); out_ids int32 [B][T] = collapsed ids padded with -1, out_len int32 [B] */
+int av_ctc_greedy(const float* log_probs, const long long* lengths, int* out_ids, int* out_len, int B, int T, int V, int blank,
+                  void* stream);
 int av_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, void* stream);
 /* multi-tensor form (one launch per step): ptrs [n_tensors][5] device pointers {param, grad, exp_avg, exp_avg_sq, shadow};

@@ -19,8 +19,20 @@ def simple_beam_search(log_probs: torch.Tensor, beam_width=5, blank=0):
     return out
 
 
-def greedy_batch(log_probs: torch.Tensor, blank: int):
-    """[B,T,V] -> list of B id lists (one device argmax + one transfer for the whole batch)."""
+def greedy_batch(log_probs: torch.Tensor, blank: int, lengths: torch.Tensor = None):
+    """[B,T,V] -> list of B id lists.  On the GPU: argmax + collapse in one HIP kernel (decode.hip), only the collapsed ids and
+    their counts travel to the host."""
+    if log_probs.is_cuda and log_probs.dim() == 3 and log_probs.shape[1] <= 4096:
+        from . import _lib as L
+        from . import ops
+        lp = log_probs.detach().float().contiguous()
+        B, T, V = lp.shape
+        out = torch.empty((B, T), dtype=torch.int32, device=lp.device)
+        cnt = torch.empty((B,), dtype=torch.int32, device=lp.device)
+        ln = None if lengths is None else lengths.to(device=lp.device, dtype=torch.long).contiguous()
+        L.check(L.lib().av_ctc_greedy(ops.ptr(lp), ops.ptr(ln), ops.ptr(out), ops.ptr(cnt), B, T, V, int(blank), ops.stream()), "av_ctc_greedy")
+        out_h, cnt_h = out.cpu(), cnt.cpu().tolist()
+        return [out_h[i, :cnt_h[i]].tolist() for i in range(B)]
     ids = torch.argmax(log_probs, dim=-1).cpu().tolist()
     res = []
     for row in ids:

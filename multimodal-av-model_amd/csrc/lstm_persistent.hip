@@ -29,12 +29,37 @@ struct PB {
     int T, B;
 };
 
+// ---- exchange protocol.  AV_LSTM_SC1 = 1: the tensors other workgroups read (h_t forward, dgates_t backward) are written and
+// read with agent-coherent accesses (sc0 sc1: write-through stores, cache-bypassing loads), so the hand-off needs no L2
+// write-back (release fence) and no L2 invalidate (acquire fence): the producer drains its stores (vmcnt(0)) and bumps the
+// counter, the consumer polls the counter and then issues the coherent loads.  AV_LSTM_SC1 = 0: plain accesses + agent fences.
+#ifndef AV_LSTM_SC1
+#define AV_LSTM_SC1 1
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 load16_coherent(const void* ptr) {      // the caller waits (s_waitcnt vmcnt) before using the value
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void store4_coherent(void* ptr, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(ptr), "v"(v) : "memory");
+}
+// two adjacent lanes (r, r^1) hold consecutive bf16 elements: the even lane stores both as one coherent dword
+__device__ __forceinline__ void store_bf16_pair_coherent(bf16_t* ptr_even_elem, float v, int r) {
+    const unsigned mine = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)v);
+    const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
+    if ((r & 1) == 0) store4_coherent(ptr_even_elem, mine | (other << 16));
+}
+
 __device__ __forceinline__ void publish(int* counter, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every wave: my stores have left
     __syncthreads();
     if (tid == 0) {
+#if !AV_LSTM_SC1
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -46,7 +71,9 @@ __device__ __forceinline__ void wait_for(int* counter, int target, int* flag, in
             __builtin_amdgcn_s_sleep(2);
             if (++spins > SPIN_LIMIT) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
+#if !AV_LSTM_SC1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -113,6 +140,27 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
             if (s > 0) {
                 // h_{t-1}[mbase .. mbase+64) x 512 -> LDS, fully coalesced (one 1-KiB row per 64 lanes)
                 const bf16_t* hprev = p.hseq + ((long long)tp * B) * 2 * H + d * H;
+#if AV_LSTM_SC1
+                {
+                    constexpr int NIT = 64 * (H / 8) / 256;
+                    u32x4 hv[NIT];
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int i = it * 256 + tid;
+                        const int row = i / (H / 8), ch = i % (H / 8);
+                        const int rr = mbase + row < B ? mbase + row : B - 1;           // rows >= B are zeroed below
+                        hv[it] = load16_coherent(hprev + (long long)rr * 2 * H + ch * 8);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int i = it * 256 + tid;
+                        const int row = i / (H / 8), ch = i % (H / 8);
+                        if (mbase + row >= B) hv[it] = u32x4{0u, 0u, 0u, 0u};
+                        *(u32x4*)(Al + row * ALD + ch * 8) = hv[it];
+                    }
+                }
+#else
 #pragma unroll
                 for (int it = 0; it < 64 * (H / 8) / 256; ++it) {
                     const int i = it * 256 + tid;
@@ -121,6 +169,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
                     if (mbase + row < B) v = *(const uint4*)(hprev + (long long)(mbase + row) * 2 * H + ch * 8);
                     *(uint4*)(Al + row * ALD + ch * 8) = v;
                 }
+#endif
                 __syncthreads();
                 const bf16_t* arow = Al + (w * 16 + r) * ALD + 8 * g;          // wave w = row tile w, full K
 #pragma unroll
@@ -154,7 +203,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
                     const float og = sigmoid_fast(acc[3][e] + gxv[3]);
                     const float c = fg * cprev + ig * gg;
                     const float h = og * tanh_fast(c);
+#if AV_LSTM_SC1
+                    store_bf16_pair_coherent(p.hseq + ((long long)td * B + row) * 2 * H + d * H + j, h, r);   // the only store others wait for
+#else
                     p.hseq[((long long)td * B + row) * 2 * H + d * H + j] = (bf16_t)h;      // the only store other workgroups wait for
+#endif
                     if (defer) { sv[e][0] = c; sv[e][1] = h; sv[e][2] = ig; sv[e][3] = fg; sv[e][4] = gg; sv[e][5] = og; }
                     else store_rest(p, td, row, d, j, c, h, ig, fg, gg, og);
                 }
@@ -214,6 +267,28 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             if (s > 0) {                                            // dh_rec = dgates[tn] x W_hh, K = 4H in 8 double-buffered chunks
                 const bf16_t* A = p.dgates + (((long long)tn * B) * 2 + d) * 4 * H;          // row stride 8H
+#if AV_LSTM_SC1
+                u32x4 st[CPT];
+                auto gload = [&](int c) {
+#pragma unroll
+                    for (int it = 0; it < CPT; ++it) {
+                        const int i = it * 256 + tid;
+                        const int row = i / (BCH / 8), ch = i % (BCH / 8);
+                        const int rr = mbase + row < B ? mbase + row : B - 1;           // rows >= B are zeroed in lstore
+                        st[it] = load16_coherent(A + (long long)rr * 8 * H + c * BCH + ch * 8);
+                    }
+                };
+                auto lstore = [&](int buf) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the coherent loads above are inline asm
+#pragma unroll
+                    for (int it = 0; it < CPT; ++it) {
+                        const int i = it * 256 + tid;
+                        const int row = i / (BCH / 8), ch = i % (BCH / 8);
+                        if (mbase + row >= B) st[it] = u32x4{0u, 0u, 0u, 0u};
+                        *(u32x4*)(Ab + (buf * 64 + row) * BLD + ch * 8) = st[it];
+                    }
+                };
+#else
                 uint4 st[CPT];
                 auto gload = [&](int c) {
 #pragma unroll
@@ -232,6 +307,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
                         *(uint4*)(Ab + (buf * 64 + row) * BLD + ch * 8) = st[it];
                     }
                 };
+#endif
                 gload(0);
                 lstore(0);
                 __syncthreads();
@@ -272,10 +348,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
                     const float dcs = dcold + dh * og * (1.f - tc * tc);
                     *dcp = dcs * fg;
                     bf16_t* dg = p.dgates + (((long long)td * B + row) * 2 + d) * 4 * H;
+#if AV_LSTM_SC1
+                    store_bf16_pair_coherent(dg + j, dcs * gg * ig * (1.f - ig), r);
+                    store_bf16_pair_coherent(dg + H + j, dcs * cprev * fg * (1.f - fg), r);
+                    store_bf16_pair_coherent(dg + 2 * H + j, dcs * ig * (1.f - gg * gg), r);
+                    store_bf16_pair_coherent(dg + 3 * H + j, dh * tc * og * (1.f - og), r);
+#else
                     dg[j] = (bf16_t)(dcs * gg * ig * (1.f - ig));
                     dg[H + j] = (bf16_t)(dcs * cprev * fg * (1.f - fg));
                     dg[2 * H + j] = (bf16_t)(dcs * ig * (1.f - gg * gg));
                     dg[3 * H + j] = (bf16_t)(dh * tc * og * (1.f - og));
+#endif
                 }
             }
             __syncthreads();

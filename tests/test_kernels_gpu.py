@@ -335,3 +335,20 @@ def test_conv3x3_c64_weights_stationary(n_img, H, W):
     L.check(L.lib().av_conv3x3_c64(ops.ptr(xi), ops.ptr(wki), ops.ptr(y), None, n_img, H, W, ops.stream()), "av_conv3x3_c64")
     refi = torch.nn.functional.conv2d(xi.double().permute(0, 3, 1, 2), wi.double(), padding=1).permute(0, 2, 3, 1).reshape(M, 64)
     torch.testing.assert_close(y.double(), refi.to(torch.bfloat16).double(), rtol=0, atol=0)
+
+
+def test_ctc_greedy_on_device():
+    """decode.hip against the host restatement of the reference's decode (argmax path, collapse repeats, drop blanks), with ties
+    (first maximal index) and per-item lengths."""
+    bs = pkg("beam_search")
+    B, T, V = 5, 37, 800
+    lp = torch.log_softmax(_rand(B, T, V) * 3, -1)
+    lp[0, 3, 10] = lp[0, 3].max() + 1; lp[0, 4, 10] = lp[0, 4].max() + 1          # a repeat to collapse
+    lp[1, 5, 7] = 5.0; lp[1, 5, 2] = 5.0                                            # a tie: index 2 wins
+    lp[2, :, 3] = 9.0                                                               # all blank (blank = 3)
+    want = [bs.simple_beam_search(lp[i], 5, 3) for i in range(B)]
+    assert bs.greedy_batch(lp, 3) == want
+    lens = torch.tensor([37, 20, 5, 0, 11], device="cuda")
+    want_l = [bs.simple_beam_search(lp[i, : int(lens[i])], 5, 3) if int(lens[i]) else [] for i in range(B)]
+    assert bs.greedy_batch(lp, 3, lens) == want_l
+    assert bs.greedy_batch(lp.cpu(), 3) == want                                     # host tensors keep the old path
