@@ -96,7 +96,10 @@ __device__ __forceinline__ void store_rest(const PF& p, int td, int row, int d, 
 }
 
 constexpr int ALD = H + 8;                  // forward A tile row (64 rows x 520 bf16)
-constexpr int BCH = 256, BLD = BCH + 8;     // backward A chunk: 64 rows x 256 of K = 4H, double buffered
+constexpr int DCH = 128, NDC = 4 * H / DCH, NRING = 4, DCH_BYTES = 64 * DCH * 2;   // backward A stream: 16 chunks of 64 rows x 128 k, ring of 4
+#define AV_CPOL_SC0_SC1 17                   /* cache-policy operand of the LDS-DMA builtin: sc0 (bit 0) | sc1 (bit 4) */
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
 __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Wt = (bf16_t*)smem;                                      // [16][WTLD]: row u = unit j0+u, k over the 4H gate rows
-    bf16_t* Ab = Wt + 16 * WTLD;                                     // [2][64][BLD]: K-chunks of dgates[t_next]
+    bf16_t* Ab = Wt + 16 * WTLD;                                     // ring of 4 x [64][128] chunks of dgates[t_next]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int d = blockIdx.y, j0 = blockIdx.x * 16;
@@ -241,8 +244,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
     __syncthreads();
     int* cnt = p.counters + d;
     const int j = j0 + r;
-    constexpr int NCH = 4 * H / BCH;                                 // 8 chunks
-    constexpr int CPT = 64 * (BCH / 8) / 256;                        // 16-B pieces per thread per chunk = 8
     for (int s = 0; s < T; ++s) {
         const int td = d == 0 ? T - 1 - s : s;
         const int tn = d == 0 ? td + 1 : td - 1;
@@ -265,67 +266,45 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
         if (s > 0) wait_for(cnt, NJT * s, p.counters + 2, tid);
         for (int mbase = 0; mbase < B; mbase += 64) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (s > 0) {                                            // dh_rec = dgates[tn] x W_hh, K = 4H in 8 double-buffered chunks
+            if (s > 0) {
+                // dh_rec = dgates[tn] x W_hh, K = 4H streamed through a 4-deep ring of 64 x 128 LDS chunks by LDS-DMA (coherent
+                // loads, no registers): three chunks are always in flight (a deeper ring measured the same), so the 256 KiB a workgroup pulls per step arrive at
+                // fabric bandwidth instead of one load latency per chunk.  Chunk rows are 256 B, the 16-B piece XOR-swizzled with
+                // row & 15 on the source side.  Rows >= B read row B-1 (finite) and are never stored.
                 const bf16_t* A = p.dgates + (((long long)tn * B) * 2 + d) * 4 * H;          // row stride 8H
-#if AV_LSTM_SC1
-                u32x4 st[CPT];
-                auto gload = [&](int c) {
+                const int drow = lane >> 4, dpos = lane & 15;
+                auto dma = [&](int c) {
+                    char* buf = (char*)Ab + (c % NRING) * DCH_BYTES;
 #pragma unroll
-                    for (int it = 0; it < CPT; ++it) {
-                        const int i = it * 256 + tid;
-                        const int row = i / (BCH / 8), ch = i % (BCH / 8);
-                        const int rr = mbase + row < B ? mbase + row : B - 1;           // rows >= B are zeroed in lstore
-                        st[it] = load16_coherent(A + (long long)rr * 8 * H + c * BCH + ch * 8);
+                    for (int i = 0; i < 4; ++i) {
+                        const int ii = w * 4 + i, row = ii * 4 + drow;
+                        const int rr = mbase + row < B ? mbase + row : B - 1;
+                        const bf16_t* src = A + (long long)rr * 8 * H + c * DCH + ((dpos ^ (row & 15)) << 3);
+                        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(ii * 1024));
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + off), 16, 0, AV_CPOL_SC0_SC1);
                     }
                 };
-                auto lstore = [&](int buf) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the coherent loads above are inline asm
+                dma(0); dma(1); dma(2);
 #pragma unroll
-                    for (int it = 0; it < CPT; ++it) {
-                        const int i = it * 256 + tid;
-                        const int row = i / (BCH / 8), ch = i % (BCH / 8);
-                        if (mbase + row >= B) st[it] = u32x4{0u, 0u, 0u, 0u};
-                        *(u32x4*)(Ab + (buf * 64 + row) * BLD + ch * 8) = st[it];
-                    }
-                };
-#else
-                uint4 st[CPT];
-                auto gload = [&](int c) {
+                for (int c = 0; c < NDC; ++c) {
+                    // my 4 instructions of chunk c landed (the 8 of chunks c+1, c+2 may still fly), then everybody's
+                    if (c + 2 < NDC) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // chunks c+1, c+2 may still fly
+                    else if (c + 1 < NDC) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (c + 3 < NDC) dma(c + 3);                      // ring slot (c+3) % 4 was read in iteration c-1 (barrier above)
+                    const char* arow = (const char*)Ab + (c % NRING) * DCH_BYTES + (w * 16 + r) * 256;
+                    const bf16_t* brow = Wt + r * WTLD + c * DCH + 8 * g;
 #pragma unroll
-                    for (int it = 0; it < CPT; ++it) {
-                        const int i = it * 256 + tid;
-                        const int row = i / (BCH / 8), ch = i % (BCH / 8);
-                        st[it] = make_uint4(0, 0, 0, 0);
-                        if (mbase + row < B) st[it] = *(const uint4*)(A + (long long)(mbase + row) * 8 * H + c * BCH + ch * 8);
-                    }
-                };
-                auto lstore = [&](int buf) {
-#pragma unroll
-                    for (int it = 0; it < CPT; ++it) {
-                        const int i = it * 256 + tid;
-                        const int row = i / (BCH / 8), ch = i % (BCH / 8);
-                        *(uint4*)(Ab + (buf * 64 + row) * BLD + ch * 8) = st[it];
-                    }
-                };
-#endif
-                gload(0);
-                lstore(0);
-                __syncthreads();
-#pragma unroll 1
-                for (int c = 0; c < NCH; ++c) {
-                    const int cur = c & 1;
-                    if (c + 1 < NCH) gload(c + 1);                  // global loads in flight during the MFMAs of chunk c
-                    const bf16_t* arow = Ab + (cur * 64 + w * 16 + r) * BLD + 8 * g;
-                    const bf16_t* brow = Wt + r * WTLD + c * BCH + 8 * g;
-#pragma unroll
-                    for (int kk = 0; kk < BCH / 32; ++kk) {
-                        const bf16x8 a = *(const bf16x8*)(arow + kk * 32);
+                    for (int kk = 0; kk < DCH / 32; ++kk) {
+                        const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ (r & 15)) << 4));
                         const bf16x8 bq = *(const bf16x8*)(brow + kk * 32);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc, 0, 0, 0);
                     }
-                    if (c + 1 < NCH) lstore(cur ^ 1);               // buffer cur^1 was last read in iteration c-1 (barrier below)
-                    __syncthreads();
                 }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();                         // the ring is free for the next row group / step
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -368,7 +347,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
 }
 
 constexpr int LDS_F = 64 * WLD * 2 + 64 * ALD * 2;            // 66 560 + 66 560
-constexpr int LDS_B = 16 * WTLD * 2 + 2 * 64 * BLD * 2;         // 65 792 + 67 584
+constexpr int LDS_B = 16 * WTLD * 2 + NRING * DCH_BYTES;         // 65 792 + 65 536
 
 }  // namespace
 
