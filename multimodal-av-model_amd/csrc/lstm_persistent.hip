@@ -95,11 +95,11 @@ __device__ __forceinline__ void store_rest(const PF& p, int td, int row, int d, 
     }
 }
 
-constexpr int ALD = H + 8;                  // forward A tile row (64 rows x 520 bf16)
-constexpr int DCH = 128, NDC = 4 * H / DCH, NRING = 4, DCH_BYTES = 64 * DCH * 2;   // backward A stream: 16 chunks of 64 rows x 128 k, ring of 4
 #define AV_CPOL_SC0_SC1 17                   /* cache-policy operand of the LDS-DMA builtin: sc0 (bit 0) | sc1 (bit 4) */
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int ALD = H + 8;                  // forward A tile row (64 rows x 520 bf16)
+constexpr int DCH = 128, NDC = 4 * H / DCH, NRING = 4, DCH_BYTES = 64 * DCH * 2;   // backward A stream: 16 chunks of 64 rows x 128 k, ring of 4
 
 __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -144,24 +144,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
                 // h_{t-1}[mbase .. mbase+64) x 512 -> LDS, fully coalesced (one 1-KiB row per 64 lanes)
                 const bf16_t* hprev = p.hseq + ((long long)tp * B) * 2 * H + d * H;
 #if AV_LSTM_SC1
-                {
-                    constexpr int NIT = 64 * (H / 8) / 256;
-                    u32x4 hv[NIT];
+                {   // coherent LDS-DMA, one 1-KiB row per wave instruction (16 per wavefront), 16-B piece XOR-swizzled with row & 15 on
+                    // the source side; rows >= B read row B-1 and are never stored
+                    const int pos = lane;
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const int i = it * 256 + tid;
-                        const int row = i / (H / 8), ch = i % (H / 8);
-                        const int rr = mbase + row < B ? mbase + row : B - 1;           // rows >= B are zeroed below
-                        hv[it] = load16_coherent(hprev + (long long)rr * 2 * H + ch * 8);
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = w * 16 + i;
+                        const int rr = mbase + row < B ? mbase + row : B - 1;
+                        const bf16_t* src = hprev + (long long)rr * 2 * H + ((pos ^ (row & 15)) << 3);
+                        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(row * 1024));
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)((char*)Al + off), 16, 0, AV_CPOL_SC0_SC1);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const int i = it * 256 + tid;
-                        const int row = i / (H / 8), ch = i % (H / 8);
-                        if (mbase + row >= B) hv[it] = u32x4{0u, 0u, 0u, 0u};
-                        *(u32x4*)(Al + row * ALD + ch * 8) = hv[it];
-                    }
                 }
 #else
 #pragma unroll
@@ -174,10 +168,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
                 }
 #endif
                 __syncthreads();
+#if AV_LSTM_SC1
+                const char* arow = (const char*)Al + (w * 16 + r) * 1024;      // wave w = row tile w, full K (swizzled 1-KiB rows)
+#else
                 const bf16_t* arow = Al + (w * 16 + r) * ALD + 8 * g;          // wave w = row tile w, full K
+#endif
 #pragma unroll
                 for (int kk = 0; kk < H / 32; ++kk) {
+#if AV_LSTM_SC1
+                    const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ (r & 15)) << 4));
+#else
                     const bf16x8 a = *(const bf16x8*)(arow + kk * 32);
+#endif
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const bf16x8 bq = *(const bf16x8*)(Wl + (q * 16 + r) * WLD + kk * 32 + 8 * g);
