@@ -54,19 +54,45 @@ __global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
     for (int oyt = 0; oyt < ntile; ++oyt) {
         const int oy0 = oyt * TOY;
         __syncthreads();                                        // previous tile's image reads are done
-        for (int i = tid; i < KT * PH * (PW / 4); i += 256) {       // 4 consecutive patch pixels per thread
-            const int pc = i % (PW / 4), q = i / (PW / 4);
-            const int py = q % PH, kt = q / PH;
-            const int ti = t + kt - 2, iy = 2 * oy0 - 3 + py, ix0 = 2 * ox0 - 3 + pc * 4;
-            const bool rowok = ti >= 0 && ti < p.T && iy >= 0 && iy < p.H;
-            const float* src = p.x + ((long long)(bt + kt - 2) * p.H + iy) * p.W;
-            bf16x4 o;
+        {   // 4 consecutive patch pixels per thread and iteration; ALL global loads are issued before the first LDS write (a
+            // load -> convert -> write loop pays one memory round trip per iteration)
+            constexpr int NPATCH = KT * PH * (PW / 4), NIT = (NPATCH + 255) / 256;
+            float pv[NIT][4];
+            bool ok[NIT][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ix = ix0 + e;
-                o[e] = (bf16_t)((rowok && ix >= 0 && ix < p.W) ? src[ix] : 0.f);
+            for (int it = 0; it < NIT; ++it) {
+                const int i = it * 256 + tid;
+                const int pc = i % (PW / 4), q = i / (PW / 4);
+                const int py = q % PH, kt = q / PH;
+                const int ti = t + kt - 2, iy = 2 * oy0 - 3 + py, ix0 = 2 * ox0 - 3 + pc * 4;
+                const bool rowok = i < NPATCH && ti >= 0 && ti < p.T && iy >= 0 && iy < p.H;
+                // unconditional loads from clamped (always valid) addresses + select: predicated loads compile to one
+                // branch + vmcnt(0) each, i.e. 20 serial memory round trips per tile
+                const int tic = ti < 0 ? 0 : (ti > p.T - 1 ? p.T - 1 : ti), iyc = iy < 0 ? 0 : (iy > p.H - 1 ? p.H - 1 : iy);
+                const float* src = p.x + ((long long)(bt - t + tic) * p.H + iyc) * p.W;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ix = ix0 + e;
+                    const int ixc = ix < 0 ? 0 : (ix > p.W - 1 ? p.W - 1 : ix);
+                    pv[it][e] = src[ixc];
+                    ok[it][e] = rowok && ix >= 0 && ix < p.W;
+                }
             }
-            *(bf16x4*)(patch + (kt * PH + py) * PW + pc * 4) = o;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)                          // pin: keeps the loads unconditional and batched
+                asm volatile("" :: "v"(pv[it][0]), "v"(pv[it][1]), "v"(pv[it][2]), "v"(pv[it][3]));
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = it * 256 + tid;
+                if (i < NPATCH) {
+                    const int pc = i % (PW / 4), q = i / (PW / 4);
+                    const int py = q % PH, kt = q / PH;
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(ok[it][e] ? pv[it][e] : 0.f);
+                    *(bf16x4*)(patch + (kt * PH + py) * PW + pc * 4) = o;
+                }
+            }
         }
         __syncthreads();
         f32x4 acc[2][4];
@@ -97,16 +123,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
                 for (int e = 0; e < 4; ++e)
                     cs[((2 * w + i) * 16 + 4 * g + e) * CLD + j * 16 + r] = acc[i][j][e];   // pixel = oy_l*16 + ox_l
         __syncthreads();
+        {   // all LDS reads first, into distinct registers: a store whose data registers are reused by the next read costs a
+            // vmcnt(0) round trip per iteration
+            uint4 ov[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int id = it * 256 + tid;
-            const int pix = id >> 3, cc = (id & 7) * 8;
-            const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
-            const f32x4 v0 = *(const f32x4*)(cs + pix * CLD + cc), v1 = *(const f32x4*)(cs + pix * CLD + cc + 4);
-            bf16x8 o;
+            for (int it = 0; it < 4; ++it) {
+                const int id = it * 256 + tid;
+                const int pix = id >> 3, cc = (id & 7) * 8;
+                const f32x4 v0 = *(const f32x4*)(cs + pix * CLD + cc), v1 = *(const f32x4*)(cs + pix * CLD + cc + 4);
+                bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v0[e]; o[4 + e] = (bf16_t)v1[e]; }
-            *(bf16x8*)(p.y + (((long long)bt * p.Ho + oy) * p.Wo + ox) * 64 + cc) = o;
+                for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v0[e]; o[4 + e] = (bf16_t)v1[e]; }
+                ov[it] = __builtin_bit_cast(uint4, o);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) asm volatile("" :: "v"(ov[it].x), "v"(ov[it].y), "v"(ov[it].z), "v"(ov[it].w));
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int id = it * 256 + tid;
+                const int pix = id >> 3, cc = (id & 7) * 8;
+                const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+                *(uint4*)(p.y + (((long long)bt * p.Ho + oy) * p.Wo + ox) * 64 + cc) = ov[it];
+            }
         }
         if (p.stats) {                                           // 4 row groups x 64 columns, combined through LDS
             const int c = tid & 63, rg = tid >> 6;
