@@ -185,19 +185,29 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
 
     // ---- phase A operands: Q and dO images, delta and LSE per query
     stage_img(I0, Q, p.q_rs, p.Tq, RA, tid);
-    for (int c0 = tid; c0 < RA * 8; c0 += NT) {                 // 8 consecutive lanes share a row
-        const int row = c0 >> 3, ch = c0 & 7;
-        bf16x8 dv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        float s = 0.f;
-        if (row < p.Tq) {
-            dv = *(const bf16x8*)(DO + (long long)row * p.do_rs + ch * 8);
-            const bf16x8 ov = *(const bf16x8*)(O + (long long)row * p.o_rs + ch * 8);
+    for (int cb = tid; cb < RA * 8; cb += 4 * NT) {             // 8 consecutive lanes share a row; 4 rows per thread in flight:
+        bf16x8 dvv[4], ovv[4];                                  // unconditional loads from clamped rows first, select afterwards
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float)dv[e] * (float)ov[e];
+        for (int u = 0; u < 4; ++u) {
+            const int c0 = cb + u * NT, row = c0 >> 3, ch = c0 & 7;
+            const int rr = row < p.Tq ? row : p.Tq - 1;
+            dvv[u] = *(const bf16x8*)(DO + (long long)rr * p.do_rs + ch * 8);
+            ovv[u] = *(const bf16x8*)(O + (long long)rr * p.o_rs + ch * 8);
         }
-        *(bf16x8*)(I1 + swz(row, ch)) = dv;
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        if (ch == 0) del_s[row] = s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c0 = cb + u * NT, row = c0 >> 3, ch = c0 & 7;
+            if (c0 < RA * 8) {                                  // wave-uniform (RA * 8 and NT are multiples of 64)
+                const bool ok = row < p.Tq;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)dvv[u][e] * (float)ovv[u][e];
+                s = ok ? s : 0.f;
+                *(bf16x8*)(I1 + swz(row, ch)) = ok ? dvv[u] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+                if (ch == 0) del_s[row] = s;
+            }
+        }
     }
     for (int i = tid; i < R; i += NT) lse_s[i] = i < p.Tq ? lse[i] * LOG2E : 0.f;
     __syncthreads();
