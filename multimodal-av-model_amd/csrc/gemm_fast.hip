@@ -325,7 +325,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
     // Fast tails: a store whose data registers are reused by the next iteration's LDS reads makes the compiler drain vmcnt(0)
     // in between, i.e. one store round trip per iteration.  For the common epilogues all rows are therefore produced first
     // (distinct registers) and stored together.
-    if (n0 + BNT <= p.N && fl.c_vec && !p.C2 && p.act == AV_ACT_NONE && p.drop_p <= 0.f && !R && !p.stats && p.out_dtype == AV_BF16) {
+    const bool fast_tail = n0 + BNT <= p.N && fl.c_vec && !p.C2 && p.act == AV_ACT_NONE && p.drop_p <= 0.f && !R && p.out_dtype == AV_BF16;
+    if (fast_tail) {
         constexpr int NIT = BM * CPR / NT;
         uint4 ov[NIT];
         const int cc = (tid % CPR) * 8;
@@ -345,8 +346,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
             const int row = (it * NT + tid) / CPR;
             if (m0 + row < p.M) *(uint4*)((bf16_t*)p.C + cbase + (long long)(m0 + row) * p.ldc + n0 + cc) = ov[it];
         }
-        return;
     }
+    if (!fast_tail)
 #pragma unroll
     for (int it = 0; it < BM * CPR / NT; ++it) {
         const int id = it * NT + tid;
