@@ -158,23 +158,33 @@ __global__ __launch_bounds__(256) void bn_prelu_maxpool_vec_kernel(const bf16x8*
         const int ox = (int)(q % Wo); q /= Wo;
         const int oy = (int)(q % Ho);
         const long long img = q / Ho;
+        // the 9 taps are loaded unconditionally from clamped (valid) coordinates and masked afterwards: a predicated load compiles
+        // to a branch + vmcnt(0), i.e. nine serial memory round trips per output
+        bf16x8 tap[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy, iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx, ixc = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+                tap[dy * 3 + dx] = x[((img * H + iyc) * W + ixc) * C8 + cgi];
+            }
+        }
         float m[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int iy = oy * 2 - 1 + dy;
-            if (iy < 0 || iy >= H) continue;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int ix = ox * 2 - 1 + dx;
-                if (ix < 0 || ix >= W) continue;
-                const bf16x8 xv = x[((img * H + iy) * W + ix) * C8 + cgi];
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;     // a clamped duplicate never changes the max; masked anyway
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    float v = (float)xv[i] * sc[i] + sh[i];
+                    float v = (float)tap[dy * 3 + dx][i] * sc[i] + sh[i];
                     v = v >= 0.f ? v : v * sl[i];
-                    m[i] = fmaxf(m[i], v);
+                    m[i] = ok ? fmaxf(m[i], v) : m[i];
                 }
             }
         }
