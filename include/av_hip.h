@@ -91,10 +91,10 @@ int av_transpose(const void* in, int idt, void* out, int odt, int R, int C, long
 int av_layernorm_fwd(const void* x, int xdt, const float* gamma, const float* beta, void* y, int ydt,
                      float* mean, float* rstd, long long rows, int cols, float eps, int act, void* stream);
 /* dx = dres + LN'(dy) (dres optional fp32); dgamma/dbeta partials [nblk][2][cols] (optional; reduce with
- * av_colsum). x fp32/bf16 (xdt), dy dtype dydt, dx fp32. */
+ * av_colsum). x fp32/bf16 (xdt), dy dtype dydt, dx fp32; dx_bf16 (optional): bf16 copy of dx for the next GEMM. */
 int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk,
-                     long long rows, int cols, void* stream);
+                     long long rows, int cols, void* dx_bf16, void* stream);
 /* F.log_softmax(dim=-1) (model/decoder.py:25) and its backward: dx = dy - exp(y) * sum(dy) */
 int av_log_softmax_fwd(const void* x, int xdt, float* y, long long rows, int cols, void* stream);
 int av_log_softmax_bwd(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, void* stream);

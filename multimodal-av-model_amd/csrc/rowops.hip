@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ dres,
                                                          float* __restrict__ dx, float* __restrict__ dgb, long long rows,
-                                                         long long rows_per_block) {
+                                                         long long rows_per_block, bf16_t* __restrict__ dxl) {
     constexpr int cols = NV * 256;
     __shared__ float red[4][2][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -217,6 +217,12 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
                 for (int e = 0; e < 4; ++e) o[e] += rr[e];
             }
             *(f32x4*)(dx + off) = o;
+            if (dxl) {                                       // bf16 copy for the GEMM that consumes dx next (saves a cast pass)
+                bf16x4 ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ol[e] = (bf16_t)o[e];
+                *(bf16x4*)(dxl + off) = ol;
+            }
         }
     }
     if (PG && dgb) {
@@ -469,8 +475,9 @@ extern "C" int av_layernorm_fwd(const void* x, int xdt, const float* gamma, cons
 
 extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
                                 const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk, long long rows,
-                                int cols, void* stream) {
+                                int cols, void* dx_bf16, void* stream) {
     AV_CHECK(x && dy && gamma && mean && rstd && dx, "av_layernorm_bwd: null pointer");
+    AV_CHECK(!dx_bf16 || (uintptr_t)dx_bf16 % 8 == 0, "av_layernorm_bwd: dx_bf16 must be 8-byte aligned");
     AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_layernorm_bwd: cols=%d out of range", cols);
     AV_CHECK(nblk >= 1, "av_layernorm_bwd: nblk=%d", nblk);
     if (rows == 0) return AV_OK;
@@ -481,7 +488,7 @@ extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt
         const bool da = dydt == AV_F32 ? ((uintptr_t)dy % 16 == 0) : ((uintptr_t)dy % 8 == 0);
         if ((cols == 256 || cols == 512 || cols == 1024 || cols == 2048) && xa && da && (uintptr_t)gamma % 16 == 0 && (uintptr_t)dx % 16 == 0 &&
             (!dres || (uintptr_t)dres % 16 == 0)) {
-#define LBV(N, P) hipLaunchKernelGGL((ln_bwd_vec_kernel<N, P>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx, dgb_partial, rows, rpb)
+#define LBV(N, P) hipLaunchKernelGGL((ln_bwd_vec_kernel<N, P>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx, dgb_partial, rows, rpb, (bf16_t*)dx_bf16)
 #define LBV_N(P) do { if (cols == 256) LBV(1, P); else if (cols == 512) LBV(2, P); else if (cols == 1024) LBV(4, P); else LBV(8, P); } while (0)
             if (dgb_partial) LBV_N(true); else LBV_N(false);
 #undef LBV_N
@@ -497,6 +504,7 @@ extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt
 #undef LN_BWD_N
 #undef LN_BWD
     AV_LAUNCH_CHECK();
+    if (dx_bf16) return av_cast(dx, AV_F32, dx_bf16, AV_BF16, rows * (long long)cols, stream);      // generic shapes: separate pass
     return AV_OK;
 }
 

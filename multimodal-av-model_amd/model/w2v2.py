@@ -324,10 +324,15 @@ class Wav2Vec2ModelHIP(nn.Module):
             dh = ops.layernorm_bwd(ctx["hL"], dlast.contiguous().float(), self.P("encoder.layer_norm.weight").data, ctx["muf"], ctx["rsf"])
         else:
             dh = torch.zeros((B, T, Hd), dtype=torch.float32, device=dev)
+        # bf16 perf path without hidden dropout: the LayerNorm-backward kernels also emit the bf16 copy of dh that the next dX
+        # GEMM reads (otherwise a separate cast pass per use); dh_lp is that copy when it is current
+        fuse_lp = dtype == torch.bfloat16 and ctx["hd_p"] == 0
+        dh_lp = None
         dmid_c = dmid.contiguous().float() if dmid is not None else None
         for li in range(nl - 1, ctx["first"] - 1, -1):
             if dmid_c is not None and 6 <= li + 1 <= 9 and li + 1 < nl:
                 ops.axpby(0.25, dmid_c, 1.0, dh)
+                dh_lp = None                                         # dh changed after its bf16 copy was written
             s = ctx["saved"][li]
             if isinstance(s, str):                                   # LayerDrop skipped this layer: identity
                 continue
@@ -336,7 +341,7 @@ class Wav2Vec2ModelHIP(nn.Module):
             M = B * T
             seed, hd_p, at_p, ac_p = ctx["seed"], ctx["hd_p"], ctx["at_p"], ctx["ac_p"]
             dh3 = dh
-            dh3_t = ops.cast_dropout(dh3, dtype, (hd_p, seed, li * 8 + 2))       # the FFN-output dropout mask of the forward
+            dh3_t = dh_lp if (fuse_lp and dh_lp is not None) else ops.cast_dropout(dh3, dtype, (hd_p, seed, li * 8 + 2))   # FFN-output dropout mask
             W2 = self.c(p + "feed_forward.output_dense.weight", dtype)            # [Hd, I]
             du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I), b_is_weight=True,
                                drop=(ac_p, seed, li * 8 + 1))
@@ -349,12 +354,16 @@ class Wav2Vec2ModelHIP(nn.Module):
                 grads[p + "feed_forward.intermediate_dense.weight"] = ops.matmul_tn(du, s["x2"].view(M, Hd))
                 grads[p + "feed_forward.intermediate_dense.bias"] = ops.colsum(du)
             r = ops.layernorm_bwd(s["h2"], dx2.view(B, T, Hd), self.P(p + "final_layer_norm.weight").data, s["mu2"], s["rs2"], dres=dh3,
-                                  want_param_grads=tr)
+                                  want_param_grads=tr, lp_copy=fuse_lp)
+            dh2_lp = None
+            if fuse_lp:
+                r, dh2_lp = r[:-1], r[-1]
+                r = r if tr else r[0]
             if tr:
                 dh2, grads[p + "final_layer_norm.weight"], grads[p + "final_layer_norm.bias"] = r
             else:
                 dh2 = r
-            dh2_t = ops.cast_dropout(dh2, dtype, (hd_p, seed, li * 8 + 0))
+            dh2_t = dh2_lp if dh2_lp is not None else ops.cast_dropout(dh2, dtype, (hd_p, seed, li * 8 + 0))
             Wo = self.c(p + "attention.out_proj.weight", dtype)
             dao = ops.matmul_nn(dh2_t.view(M, Hd), Wo, out_dtype=dtype, b_is_weight=True).view(B, T, nh, hd)
             if tr:
@@ -372,7 +381,11 @@ class Wav2Vec2ModelHIP(nn.Module):
                     grads[p + f"attention.{n}_proj.weight"] = dW[j * Hd:(j + 1) * Hd]
                     grads[p + f"attention.{n}_proj.bias"] = db[j * Hd:(j + 1) * Hd]
             r = ops.layernorm_bwd(s["h"], dx1.view(B, T, Hd), self.P(p + "layer_norm.weight").data, s["mu1"], s["rs1"], dres=dh2,
-                                  want_param_grads=tr)
+                                  want_param_grads=tr, lp_copy=fuse_lp)
+            dh_lp = None
+            if fuse_lp:
+                r, dh_lp = r[:-1], r[-1]
+                r = r if tr else r[0]
             if tr:
                 dh, grads[p + "layer_norm.weight"], grads[p + "layer_norm.bias"] = r
             else:

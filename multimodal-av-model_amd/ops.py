@@ -234,19 +234,24 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, *, out_dtype: torch.dt
 
 
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
-                  want_param_grads: bool = False):
+                  want_param_grads: bool = False, lp_copy: bool = False):
+    """dx (fp32) [, dgamma, dbeta]; with ``lp_copy`` the last element returned is a bf16 copy of dx written by the same kernel."""
     cols = x.shape[-1]
     rows = x.numel() // cols
     assert x.is_contiguous() and dy.is_contiguous()
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dxl = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if lp_copy else None
     nblk = max(1, min(512, (rows + 15) // 16))
     part = torch.empty((nblk, 2 * cols), dtype=torch.float32, device=x.device) if want_param_grads else None
     L.check(L.lib().av_layernorm_bwd(ptr(x), dt(x), ptr(dy), dt(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-                                     ptr(part), nblk, rows, cols, stream()), "av_layernorm_bwd")
+                                     ptr(part), nblk, rows, cols, ptr(dxl), stream()), "av_layernorm_bwd")
+    res = (dx,)
     if want_param_grads:
         gb = colsum(part)
-        return dx, gb[:cols], gb[cols:]
-    return dx
+        res = (dx, gb[:cols], gb[cols:])
+    if lp_copy:
+        return res + (dxl,)
+    return res if want_param_grads else dx
 
 
 def log_softmax_fwd(x: Tensor) -> Tensor:

@@ -155,6 +155,9 @@ def test_layernorm_fwd_bwd(xdt, cols):
     dy = _rand(rows, cols); dres = _rand(rows, cols)
     ref.backward(dy)
     dx, dg, db = ops.layernorm_bwd(x, dy, g, mean, rstd, dres, want_param_grads=True)
+    dx2, dg2, db2, dxl = ops.layernorm_bwd(x, dy, g, mean, rstd, dres, want_param_grads=True, lp_copy=True)      # + bf16 copy of dx
+    torch.testing.assert_close(dx2, dx, rtol=0, atol=0); torch.testing.assert_close(dxl, dx.to(torch.bfloat16), rtol=0, atol=0)
+    assert ops.layernorm_bwd(x, dy, g, mean, rstd, dres, lp_copy=True)[1].dtype == torch.bfloat16
     torch.testing.assert_close(dx, xr.grad + dres, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dg, gr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(db, br.grad, rtol=1e-4, atol=1e-4)
