@@ -109,6 +109,7 @@ class VisualEncoder(nn.Module):
         self.trunk = ResNet(BasicBlock, [2, 2, 2, 2], relu_type=relu_type)
         self.output_dim = 512
         self._wcache = {}
+        self._nbt = []
 
     # conv weight [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin] (tap-major K = the NHWC im2col order), compute dtype, cached
     def _w(self, conv: nn.Module, dtype):
@@ -149,7 +150,7 @@ class VisualEncoder(nn.Module):
                                        ops.ptr(bn.running_mean), ops.ptr(bn.running_var), float(bn.momentum), float(bn.eps),
                                        int(training), ops.ptr(scale), ops.ptr(shift), C, ops.ptr(ws), ops.stream()), "av_bn_finalize")
         if training:
-            bn.num_batches_tracked += 1
+            self._nbt.append(bn.num_batches_tracked)        # bumped once per forward with one multi-tensor add (27 tiny launches otherwise)
         return scale, shift
 
     def _conv2d(self, x, N, H, W, Cin, conv: nn.Module, dtype, training: bool):
@@ -182,6 +183,7 @@ class VisualEncoder(nn.Module):
 
     @torch.no_grad()
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
+        self._nbt = []
         dtype = compute_dtype()
         training = self.training            # .train() on the frozen encoder => batch statistics + running-stat update
         B, C, T, H, W = x.shape
@@ -229,6 +231,9 @@ class VisualEncoder(nn.Module):
                 else:
                     h = self._act(c2, s2, b2, slope, res=h)
                 Hc, Wc, Cc = H1, W1, blk.conv1.out_channels
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+            self._nbt = []
         out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
         L.check(L.lib().av_avgpool(ops.ptr(h), ops.dt(h), ops.ptr(out), N, Hc * Wc, Cc, ops.stream()), "av_avgpool")
         return out.view(B, T, Cc)
