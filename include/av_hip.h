@@ -180,9 +180,11 @@ int av_conv3d_front(const float* x, const void* w, void* y, float* stats, int B,
  * x bf16 NHWC [n_img][H][W][64], w bf16 [64][9*64] with k = (ky*3+kx)*64 + c, y bf16 [n_img*H*W][64],
  * stats [ceil(n_img*H*W/256)][2][64] BatchNorm partials (optional).  Weights stay in LDS, the input is staged once per filter row. */
 int av_conv3x3_c64(const void* x, const void* w, void* y, float* stats, int n_img, int H, int W, void* stream);
+/* ws: 2C doubles of workspace.  ws_zeroed = 1: the caller guarantees ws is zero on entry (the kernel leaves it zero on exit, so one
+ * buffer zeroed once serves every BatchNorm of a stream); 0: it is cleared here first. */
 int av_bn_finalize(const float* partial, int nblk, long long count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
-                   float* shift, int C, double* ws /* 2C doubles */, void* stream);
+                   float* shift, int C, double* ws, int ws_zeroed, void* stream);
 int av_bn_act(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
               const float* rshift, const float* slope, void* out, int dtype, long long n, int C, void* stream);
 int av_bn_prelu_maxpool(const void* x, const float* scale, const float* shift, const float* slope, void* out, int dtype,

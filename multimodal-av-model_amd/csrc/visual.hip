@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     if (ry == 0 && c < C2) atomicAdd(ws + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ ws, double count, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(double* __restrict__ ws, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                    float eps, int training, float* __restrict__ scale, float* __restrict__ shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,6 +36,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, double count, 
     if (training) {
         const double mean = ws[c] / count;
         double var = ws[C + c] / count - mean * mean;
+        ws[c] = 0.0; ws[C + c] = 0.0;                          // leave the accumulators zeroed for the next layer (ws_zeroed protocol)
         if (var < 0.0) var = 0.0;
         sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
         sh = beta[c] - (float)mean * sc;
@@ -209,12 +210,12 @@ inline int ew_grid(long long n) {
 
 extern "C" int av_bn_finalize(const float* partial, int nblk, long long count, const float* gamma, const float* beta, float* running_mean,
                               float* running_var, float momentum, float eps, int training, float* scale, float* shift, int C, double* ws,
-                              void* stream) {
+                              int ws_zeroed, void* stream) {
     AV_CHECK(gamma && beta && scale && shift && C > 0, "av_bn_finalize: null pointer");
     AV_CHECK(training ? (partial != nullptr && nblk > 0 && count > 0 && ws != nullptr) : (running_mean && running_var), "av_bn_finalize: missing statistics input");
     hipStream_t st = (hipStream_t)stream;
     if (training) {
-        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { av_set_error("av_bn_finalize: memset failed"); return AV_ERR_LAUNCH; }
+        if (!ws_zeroed && hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { av_set_error("av_bn_finalize: memset failed"); return AV_ERR_LAUNCH; }
         hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * C + 63) / 64, (nblk + BNR_ROWS - 1) / BNR_ROWS), dim3(256), 0, st, partial, nblk, 2 * C, ws);
         AV_LAUNCH_CHECK();
     }

@@ -110,6 +110,7 @@ class VisualEncoder(nn.Module):
         self.output_dim = 512
         self._wcache = {}
         self._nbt = []
+        self._bn_ws = None
 
     # conv weight [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin] (tap-major K = the NHWC im2col order), compute dtype, cached
     def _w(self, conv: nn.Module, dtype):
@@ -145,10 +146,14 @@ class VisualEncoder(nn.Module):
         C = bn.num_features
         dev = bn.weight.device
         scale = torch.empty(C, dtype=torch.float32, device=dev); shift = torch.empty(C, dtype=torch.float32, device=dev)
-        ws = torch.empty(2 * C, dtype=torch.float64, device=dev) if training else None
+        ws = None
+        if training:                                          # one zeroed workspace per encoder: the finalize kernel leaves it zeroed
+            if self._bn_ws is None or self._bn_ws.device != dev:
+                self._bn_ws = torch.zeros(2 * 1024, dtype=torch.float64, device=dev)
+            ws = self._bn_ws
         L.check(L.lib().av_bn_finalize(ops.ptr(stats), nblk, count, ops.ptr(bn.weight.data), ops.ptr(bn.bias.data),
                                        ops.ptr(bn.running_mean), ops.ptr(bn.running_var), float(bn.momentum), float(bn.eps),
-                                       int(training), ops.ptr(scale), ops.ptr(shift), C, ops.ptr(ws), ops.stream()), "av_bn_finalize")
+                                       int(training), ops.ptr(scale), ops.ptr(shift), C, ops.ptr(ws), 1, ops.stream()), "av_bn_finalize")
         if training:
             self._nbt.append(bn.num_batches_tracked)        # bumped once per forward with one multi-tensor add (27 tiny launches otherwise)
         return scale, shift
@@ -184,6 +189,8 @@ class VisualEncoder(nn.Module):
     @torch.no_grad()
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
         self._nbt = []
+        if self._bn_ws is not None:
+            self._bn_ws.zero_()                                  # one clear per forward (robust against an aborted previous forward)
         dtype = compute_dtype()
         training = self.training            # .train() on the frozen encoder => batch statistics + running-stat update
         B, C, T, H, W = x.shape
