@@ -355,3 +355,38 @@ def test_ctc_greedy_on_device():
     want_l = [bs.simple_beam_search(lp[i, : int(lens[i])], 5, 3) if int(lens[i]) else [] for i in range(B)]
     assert bs.greedy_batch(lp, 3, lens) == want_l
     assert bs.greedy_batch(lp.cpu(), 3) == want                                     # host tensors keep the old path
+
+
+@pytest.mark.parametrize("T,B", [(9, 3), (12, 64), (7, 70), (5, 130)])
+def test_persistent_lstm_matches_step_kernels(T, B):
+    """lstm_persistent.hip (one launch per layer, coherent hand-off between workgroups, LDS-DMA streaming) against the per-step
+    kernels of lstm.hip on the same buffers: forward h / c / gates, backward dgates / dc; B > 64 exercises the row-group loop."""
+    H = 512
+    dt_ = torch.bfloat16
+    gx = _rand(T, B, 2, 4 * H)
+    whh = _rand(2, 4 * H, H, dtype=dt_, scale=1 / 22.0)
+    whhT = whh.transpose(1, 2).contiguous()
+    dout = _rand(B, T, 2 * H)
+    st = ops.stream()
+
+    def run(persistent):
+        hseq = torch.zeros(T, B, 2 * H, device="cuda", dtype=dt_); cseq = torch.zeros(T, B, 2, H, device="cuda")
+        gates = torch.zeros(T, B, 2, 4 * H, device="cuda", dtype=dt_); dg = torch.zeros_like(gates); dc = torch.zeros(2, B, H, device="cuda")
+        cnt = torch.zeros(3, dtype=torch.int32, device="cuda")
+        if persistent:
+            L.check(L.lib().av_lstm_fwd_layer(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates), None, ops.ptr(cnt), T, B, H, st), "fwd")
+            L.check(L.lib().av_lstm_bwd_layer(ops.ptr(dout), 0, T * 2 * H, 2 * H, ops.ptr(dg), ops.ptr(whhT), ops.ptr(gates), ops.ptr(cseq), ops.ptr(dc),
+                                              ops.ptr(cnt), T, B, H, st), "bwd")
+            torch.cuda.synchronize()
+            assert int(cnt[2]) == 0, "persistent LSTM: inter-workgroup wait timed out"
+        else:
+            for s in range(T):
+                L.check(L.lib().av_lstm_fwd_step(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates), None, 1, T, B, H, s, st), "fwd step")
+            for s in range(T):
+                L.check(L.lib().av_lstm_bwd_step(ops.ptr(dout), 0, T * 2 * H, 2 * H, ops.ptr(dg), ops.ptr(whhT), ops.ptr(gates), ops.ptr(cseq), ops.ptr(dc),
+                                                 1, T, B, H, s, st), "bwd step")
+        return hseq.float(), cseq, gates.float(), dg.float(), dc
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("h", "c", "gates", "dgates", "dc")):
+        torch.testing.assert_close(x, y, rtol=3e-2, atol=3e-2, msg=lambda m, n=name: f"{n}: {m}")
