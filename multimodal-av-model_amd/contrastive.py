@@ -24,7 +24,7 @@ WEIGHT_NEG_SUPPRESS = 0.3
 
 def _term_fwd(A_t, P_t, n_rows, n_cols):
     """returns (scalar [1] = mean_i lse_i - mean_ij s_ij, sim fp32 [n_rows, ld], lse, ld)"""
-    ld = (n_cols + 7) // 8 * 8
+    ld = (n_cols + 63) // 64 * 64          # padded columns are written as zeros by av_contrastive_dsim: K of the dA product = ld (fast GEMM)
     dev = A_t.device
     sim = torch.empty((n_rows, ld), dtype=torch.float32, device=dev)
     ops.gemm(A_t, P_t, sim, M=n_rows, N=n_cols, K=A_t.shape[1], lda=A_t.shape[1], ldb=P_t.shape[1], ldc=ld, alpha=1.0 / TEMPERATURE)
@@ -66,7 +66,9 @@ class _ContrastFn(torch.autograd.Function):
         proj = ops.linear(rows, ops.cast(pw.data.contiguous(), dtype), pb.data, out_dtype=torch.float32)
         f = torch.empty_like(proj); nrm = torch.empty(n, dtype=torch.float32, device=dev)
         L.check(L.lib().av_l2norm_fwd(ops.ptr(proj), ops.ptr(f), ops.ptr(nrm), n, E, 1e-12, ops.stream()), "av_l2norm_fwd")
-        f_t = ops.cast(f, dtype)
+        # 64 zero rows behind the last class: the dA product reads ld >= ncols rows of its class block (x zero columns of dS)
+        f_t = torch.zeros((n + 64, E), dtype=dtype, device=dev)
+        f_t[:n].copy_(f)
         total = torch.zeros(1, dtype=torch.float32, device=dev)
         terms = []
         if n1 > 0 and n2 > 0:
@@ -94,9 +96,9 @@ class _ContrastFn(torch.autograd.Function):
             # d/dS of w*(mean lse - mean S) and the 1/temperature of S = A P^T / tau
             L.check(L.lib().av_contrastive_dsim(ops.ptr(sim), ops.ptr(lse), ops.ptr(dsim), ops.dt(dsim), n1, ncols, ld,
                                                 wgt / (n1 * TEMPERATURE), ops.stream()), "av_contrastive_dsim")
-            Pm = f_t[c0:c1]
+            Pm = f_t[c0:]                                                     # ld rows are read (rows >= ncols meet zero columns)
             # dA += dS P ; dP = dS^T A
-            ops.gemm(dsim, Pm, df, M=n1, N=E, K=ncols, lda=ld, ldb=E, ldc=E, b_mode=L.B_KN, R=df, ldr=E)
+            ops.gemm(dsim, Pm, df, M=n1, N=E, K=ld, lda=ld, ldb=E, ldc=E, b_mode=L.B_KN, R=df, ldr=E)
             ops.matmul_tn(dsim[:, :ncols], f_t[:n1], out=df[c0:c1])          # dP = dS^T A  (transposes + fast GEMM)
         dproj = torch.empty_like(df)
         L.check(L.lib().av_l2norm_bwd(ops.ptr(s["f"]), ops.ptr(df), ops.ptr(s["nrm"]), ops.ptr(dproj), n, E, 1e-12, ops.stream()), "av_l2norm_bwd")
