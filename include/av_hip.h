@@ -199,6 +199,10 @@ int av_lse_rows(const float* s, float* lse, float* rowsum, long long rows, int c
 int av_contrastive_dsim(const float* s, const float* lse, void* out, int odt, long long rows, int cols, int ld, float coef,
                         void* stream);
 int av_reduce_sum(const float* x, long long n, float* out, float scale, int accumulate, void* stream);
+/* loss combination of the trainer (model/trainer.py:111-119): out3 = {sum_i nll[i] w[i] + half_lambda (c1 + c2), 2 x first-half sum,
+ * 2 x second-half sum}; nll, w fp32 [n] (n even: speaker 1 then speaker 2), c1 / c2 optional device scalars */
+int av_loss_combine(const float* nll, const float* w, const float* c1, const float* c2, float half_lambda, int n, float* out3,
+                    void* stream);
 /* greedy CTC decoding (beam_search.py:2-48; the reference's beam search returns the per-frame argmax path): log_probs fp32
  * [B][T][V], lengths optional int64 [B] (frames to decode); out_ids int32 [B][T] = collapsed ids padded with -1, out_len int32 [B] */
 int av_ctc_greedy(const float* log_probs, const long long* lengths, int* out_ids, int* out_len, int B, int T, int V, int blank,

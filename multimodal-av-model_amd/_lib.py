@@ -79,6 +79,7 @@ SIGNATURES = {
     "av_lse_rows": [vp, vp, vp, ll, i32, i32, vp],
     "av_contrastive_dsim": [vp, vp, vp, i32, ll, i32, i32, f32, vp],
     "av_reduce_sum": [vp, ll, vp, f32, i32, vp],
+    "av_loss_combine": [vp, vp, vp, vp, f32, i32, vp, vp],
     "av_ctc_greedy": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "av_adam_multi": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, f32, vp],
     "av_adam_step": [vp, vp, vp, vp, ll, f32, f32, f32, f32, i32, f32, vp],

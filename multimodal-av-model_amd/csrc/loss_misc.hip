@@ -76,6 +76,28 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
     }
 }
 
+// total = sum_i nll[i] * w[i] + half_lambda * (c1 + c2);  l1 / l2 = 2 x the two halves of the weighted sum (the per-speaker CTC means of
+// model/trainer.py:111-118 with w[i] = 1 / (2 B clamp(target_len_i, 1))); one launch instead of a dozen scalar torch ops
+__global__ __launch_bounds__(256) void loss_combine_kernel(const float* __restrict__ nll, const float* __restrict__ w, const float* __restrict__ c1,
+                                                           const float* __restrict__ c2, float half_lambda, int n, float* __restrict__ out) {
+    __shared__ float red[2][4];
+    const int hn = n / 2;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = nll[i] * w[i];
+        if (i < hn) s0 += v; else s1 += v;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3], b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        out[0] = a + b + half_lambda * ((c1 ? c1[0] : 0.f) + (c2 ? c2[0] : 0.f));
+        out[1] = 2.f * a;
+        out[2] = 2.f * b;
+    }
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                             float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -176,6 +198,13 @@ extern "C" int av_contrastive_dsim(const float* s, const float* lse, void* out, 
     AV_CHECK(s && lse && out && cols > 0 && ld >= cols, "av_contrastive_dsim: bad args");
     if (rows == 0) return AV_OK;
     hipLaunchKernelGGL(contrastive_dsim_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, out, odt, rows, cols, ld, coef);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_loss_combine(const float* nll, const float* w, const float* c1, const float* c2, float half_lambda, int n, float* out3,
+                               void* stream) {
+    AV_CHECK(nll && w && out3 && n >= 2 && n % 2 == 0, "av_loss_combine: bad args (n=%d)", n);
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nll, w, c1, c2, half_lambda, n, out3);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -12,6 +12,7 @@ Differences that do not change results:
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -40,6 +41,32 @@ def word_error_rate(refs, hyps) -> float:
         errs += prev[-1]
         words += len(r)
     return errs / max(1, words)
+
+
+_FUSED_LOSS = os.environ.get("AVAMD_FUSED_LOSS", "1") != "0"
+
+
+class _CombineFn(torch.autograd.Function):
+    """total = mean-reduced CTC of both speakers / 2 + lambda (c1 + c2) / 2 (model/trainer.py:111-119) in one kernel."""
+
+    @staticmethod
+    def forward(fctx, nll, w, c1, c2, lam):
+        out = torch.empty(3, dtype=torch.float32, device=nll.device)
+        c1f = c1.detach().reshape(1).float() if c1.is_cuda else None
+        c2f = c2.detach().reshape(1).float() if c2.is_cuda else None
+        L.check(L.lib().av_loss_combine(ops.ptr(nll.detach().contiguous()), ops.ptr(w.contiguous()), ops.ptr(c1f), ops.ptr(c2f), 0.5 * lam,
+                                        nll.numel(), ops.ptr(out), ops.stream()), "av_loss_combine")
+        fctx.save_for_backward(w)
+        fctx.lam = lam
+        total, l1, l2 = out[0].clone(), out[1].clone(), out[2].clone()
+        fctx.mark_non_differentiable(l1, l2)
+        return total, l1, l2
+
+    @staticmethod
+    def backward(fctx, g, _g1, _g2):
+        (w,) = fctx.saved_tensors
+        gc = g * (0.5 * fctx.lam)
+        return g * w, None, gc, gc, None
 
 
 class MultimodalTrainer:
@@ -202,14 +229,21 @@ class MultimodalTrainer:
             tg = torch.cat([F.pad(t1, (0, Lm - t1.shape[1])), F.pad(t2, (0, Lm - t2.shape[1]))], 0)
             tl = torch.cat([d["text1_lengths"], d["text2_lengths"]], 0)
             il_h, tl_h = batch.get("_ctc_input_lengths"), batch.get("_ctc_target_lengths")     # host copies: no device sync in ctc_loss
+            w_ctc = (0.5 / B) / tl.clamp_min(1).to(torch.float32)        # weights of the per-speaker means (before the CTC call: off the sync)
             nll = F.ctc_loss(lp12.transpose(0, 1), tg, il12 if il_h is None else il_h, tl if tl_h is None else tl_h,
                              blank=self.tokenizer.blank_id, reduction="none", zero_infinity=True)
-            per = nll / tl.clamp_min(1).to(nll.dtype)
-            l1, l2 = per[:B].mean(), per[B:].mean()
+            if nll.is_cuda and nll.dtype == torch.float32 and _FUSED_LOSS:
+                total, l1, l2 = _CombineFn.apply(nll, w_ctc, c1, c2, float(self.lambda_))    # one kernel forward, one backward
+            else:
+                per = nll / tl.clamp_min(1).to(nll.dtype)
+                l1, l2 = per[:B].mean(), per[B:].mean()
+                total = None
         else:
+            total = None
             l1 = self.ctc_loss(lp1.transpose(0, 1), d["text1"], il1, d["text1_lengths"])
             l2 = self.ctc_loss(lp2.transpose(0, 1), d["text2"], il2, d["text2_lengths"])
-        total = (l1 + l2) / 2 + self.lambda_ * (c1 + c2) / 2
+        if total is None:
+            total = (l1 + l2) / 2 + self.lambda_ * (c1 + c2) / 2
         out.update(visual_feat1=vf1, visual_feat2=vf2, audio_last=a1, audio_mid=mid1, fused1=f1, fused2=f2, input_lengths1=il1,
                    input_lengths2=il2, log_probs1=lp1, log_probs2=lp2, loss1=l1, loss2=l2, contrast1=c1, contrast2=c2, total=total)
         return out
