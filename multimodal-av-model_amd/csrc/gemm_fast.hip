@@ -83,39 +83,52 @@ __device__ __forceinline__ bf16x8 kmajor_frag(const char* tile, const KmOff& o, 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-struct ConvRows { long long pix[4]; int iy0[4], ix0[4]; };
+// per tile row handled by this lane: pointer to the (ky = 0, kx = 0) tap pixel (+ the lane's swizzled 16-B chunk) and a bit mask of
+// the taps that fall inside the image (bit ky * Kw + kx for Kh * Kw <= 32; the valid ky range for longer 1-D filters).  A K-step then costs one 64-bit add and a select per row.
+struct ConvRows { const bf16_t* rowp[4]; unsigned valid[4]; };
 
-__device__ __forceinline__ void conv_rows_init(ConvRows& cr, const av_gemm_args& p, int m0, int w, int lane) {
-    const int sub = lane >> 3;
+__device__ __forceinline__ void conv_rows_init(ConvRows& cr, const bf16_t* __restrict__ base, const av_gemm_args& p, int m0, int w, int lane) {
+    const int sub = lane >> 3, choff = ((lane & 7) ^ sub) << 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + (w * 4 + i) * 8 + sub;
+        cr.rowp[i] = base;
+        cr.valid[i] = 0u;
         if (m < p.M) {
             const int ox = m % p.cOw;
             int q = m / p.cOw;
             const int oy = q % p.cOh;
             q /= p.cOh;
-            cr.pix[i] = (long long)q * p.cH * p.cW;
-            cr.iy0[i] = oy * p.cSh - p.cPh;
-            cr.ix0[i] = ox * p.cSw - p.cPw;
-        } else { cr.pix[i] = -1; cr.iy0[i] = 0; cr.ix0[i] = 0; }
+            const int iy0 = oy * p.cSh - p.cPh, ix0 = ox * p.cSw - p.cPw;
+            cr.rowp[i] = base + (((long long)q * p.cH + iy0) * p.cW + ix0) * p.cCtot + p.cCoff + choff;
+            unsigned v = 0u;
+            if (p.cKh * p.cKw <= 32) {
+                for (int ky = 0; ky < p.cKh; ++ky)
+                    for (int kx = 0; kx < p.cKw; ++kx)
+                        if (iy0 + ky >= 0 && iy0 + ky < p.cH && ix0 + kx >= 0 && ix0 + kx < p.cW) v |= 1u << (ky * p.cKw + kx);
+            } else {                                            // long 1-D filters (Kw = 1, positional conv): valid ky range [lo, hi)
+                int lo = -iy0, hi = p.cH - iy0;
+                lo = lo < 0 ? 0 : lo; hi = hi > p.cKh ? p.cKh : hi; hi = hi < lo ? lo : hi;
+                v = (unsigned)lo | ((unsigned)hi << 16);
+            }
+            cr.valid[i] = v;
+        }
     }
 }
 
 // implicit im2col of an NHWC image: one K tile (64 channels) lies inside ONE filter tap (Cin % 64 == 0), so every
 // tile row is a contiguous 128-B run of the input pixel (or the zero line for padding / rows >= M)
-__device__ __forceinline__ void stage_conv(const bf16_t* __restrict__ base, const av_gemm_args& p, const ConvRows& cr, int k0, char* tile,
-                                           int w, int lane) {
+__device__ __forceinline__ void stage_conv(const av_gemm_args& p, const ConvRows& cr, int k0, char* tile, int w, int lane) {
     const int sub = lane >> 3, pch = lane & 7;
     const int tap = k0 / p.cCin, c0 = k0 - tap * p.cCin;
     const int ky = tap / p.cKw, kx = tap - ky * p.cKw;
-    const int choff = (pch ^ sub) << 3;
+    const long long toff = ((long long)ky * p.cW + kx) * p.cCtot + c0;          // wave-uniform
+    const bf16_t* zl = (const bf16_t*)g_zero_line + ((pch ^ sub) << 3);
+    const bool ranged = p.cKh * p.cKw > 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int iy = cr.iy0[i] + ky, ix = cr.ix0[i] + kx;
-        const bool ok = cr.pix[i] >= 0 && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-        const bf16_t* src = ok ? base + ((cr.pix[i] + (long long)iy * p.cW + ix) * p.cCtot + p.cCoff + c0 + choff)
-                               : (const bf16_t*)g_zero_line + choff;
+        const bool ok = ranged ? (tap >= (int)(cr.valid[i] & 0xffffu) && tap < (int)(cr.valid[i] >> 16)) : ((cr.valid[i] >> tap) & 1u);
+        const bf16_t* src = ok ? cr.rowp[i] + toff : zl;
         const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 4 + i) * 1024));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
     }
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
     const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
 
     ConvRows cr;
-    if constexpr (CONV) conv_rows_init(cr, p, m0, w, lane);
+    if constexpr (CONV) conv_rows_init(cr, A, p, m0, w, lane);
     int Kz = p.K;                                            // split-K: this batch's slice of k_total (the last one may be shorter)
     if constexpr (AKM && BKM) {
         if (p.k_total > 0 && p.k_total - z * p.K < Kz) Kz = p.k_total - z * p.K;
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto stage = [&](int kt, char* buf) {
-        if constexpr (CONV) stage_conv(A, p, cr, kt * BK, buf, w, lane);
+        if constexpr (CONV) stage_conv(p, cr, kt * BK, buf, w, lane);
         else if constexpr (AKM) stage_kmajor(A, p.lda, m0, p.M, kt * BK, Kz, buf, w, lane);
         else stage_rows<4>(A, p.lda, m0, p.M, kt * BK, buf, w, lane);
         if constexpr (BKM) stage_kmajor(B, p.ldb, n0, p.N, kt * BK, Kz, buf + TILE_A, w, lane);
@@ -641,7 +654,7 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     if ((akm && (p.M % 8 || p.M <= 64)) || (bkm && (p.N % 8 || p.N <= 64))) return -1;
     if (!al16(p.A) || !al16(p.B) || p.M < 1 || p.N < 1) return -1;
     if (conv) {
-        if (p.cCin % 64 || p.cCtot % 8 || p.cCoff % 8) return -1;
+        if (p.cCin % 64 || p.cCtot % 8 || p.cCoff % 8 || (p.cKh * p.cKw > 32 && (p.cKw != 1 || p.cKh > 65535))) return -1;
     } else {
         if (p.lda % 8 || p.stats) return -1;
     }
