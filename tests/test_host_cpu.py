@@ -157,3 +157,16 @@ def test_host_metadata_matches_reference_fixtures():
         md = tr.MultimodalTrainer.host_metadata(tr.MultimodalTrainer.__new__(tr.MultimodalTrainer), batch, T_enc)
         assert torch.equal(md["_ctc_input_lengths"], torch.cat([il1, il2])) and not md["_ctc_input_lengths"].is_cuda
         assert torch.equal(md["_ctc_target_lengths"], torch.cat([batch["text1_lengths"], batch["text2_lengths"]]).long())
+
+
+def test_split_k_heuristic_cpu():
+    """ops._split_k: dW-shaped products (few output tiles, K = tokens) are split, full grids and short K are not."""
+    import importlib
+    ops = importlib.import_module("multimodal-av-model_amd.ops")
+    assert ops._split_k(64, 6368, 1024 * 1024) >= 4            # 1024 x 1024 output: 64 tiles on 512 slots
+    assert ops._split_k(256, 6368, 4096 * 1024) == 2           # one tile per CU -> two
+    assert ops._split_k(1600, 6368, 6368 * 4096) == 1          # already > 3 rounds
+    assert ops._split_k(64, 600, 1024 * 1024) == 1             # K too short to be worth a partial-sum pass
+    for tiles in (1, 7, 64, 200, 511):
+        s = ops._split_k(tiles, 6368, tiles * 128 * 128)
+        assert 1 <= s <= 8 and 6368 // s >= 512
