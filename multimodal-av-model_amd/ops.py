@@ -32,7 +32,14 @@ def ptr(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (raw handle: ~10x cheaper than building a Stream object
+    per kernel launch, which at ~950 launches per step was 3 ms of host time)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
