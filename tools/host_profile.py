@@ -45,5 +45,6 @@ for _ in range(5):
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
 print(s.getvalue())
