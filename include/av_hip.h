@@ -150,9 +150,12 @@ int av_lstm_fwd_step(const float* gx, const void* whh, void* hseq, float* cseq, 
 int av_lstm_bwd_step(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgates, const void* whhT,
                      const void* gates, const float* cseq, float* dc, int dtype, int T, int B, int H, int s, void* stream);
 
-/* persistent form (bf16, H = 512): ONE launch per layer for all T steps of both directions; W_hh slices stay in LDS, steps
- * are separated by a per-direction release/acquire arrival counter (64 resident workgroups, bounded spins: counters[2] is
- * set on timeout).  counters: 3 ints of workspace.  Same buffers / results as the step kernels. */
+/* persistent form (bf16, H = 512): ONE launch per layer for all T steps of both directions.  Grid = 32 unit tiles x 2 directions x
+ * up to 4 row groups of 16 batch rows; every (direction, row group) is an independent chain of 32 resident workgroups whose steps
+ * are separated by an arrival counter (agent-coherent stores / loads, bounded spins: counters[2] is set on timeout).  W_hh slices
+ * stay in registers for the whole sequence.  counters: AV_LSTM_COUNTER_INTS ints of device workspace (zeroed by the call).
+ * Same buffers as the step kernels; results agree with them to fp32 rounding of the K-quarter partial sums. */
+#define AV_LSTM_COUNTER_INTS 512
 int av_lstm_fwd_layer(const float* gx, const void* whh, void* hseq, float* cseq, void* gates, void* out_bt, int* counters,
                       int T, int B, int H, void* stream);
 int av_lstm_bwd_layer(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgates, const void* whhT,

@@ -144,8 +144,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
                 // h_{t-1}[mbase .. mbase+64) x 512 -> LDS, fully coalesced (one 1-KiB row per 64 lanes)
                 const bf16_t* hprev = p.hseq + ((long long)tp * B) * 2 * H + d * H;
 #if AV_LSTM_SC1
-                {   // coherent LDS-DMA, one 1-KiB row per wave instruction (16 per wavefront), 16-B piece XOR-swizzled with row & 15 on
-                    // the source side; rows >= B read row B-1 and are never stored
+                if (mbase + w * 16 < B) {   // coherent LDS-DMA, one 1-KiB row per wave instruction (16 per wavefront), 16-B piece XOR-swizzled
+                    // with row & 15 on the source side; rows >= B read row B-1 and are never stored.  A wavefront stages exactly the 16
+                    // rows its own MFMAs read, so the hand-over is its own vmcnt wait (no workgroup barrier), and a wavefront whose
+                    // row tile lies past B stages and multiplies nothing.
                     const int pos = lane;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -166,13 +168,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
                     if (mbase + row < B) v = *(const uint4*)(hprev + (long long)(mbase + row) * 2 * H + ch * 8);
                     *(uint4*)(Al + row * ALD + ch * 8) = v;
                 }
-#endif
                 __syncthreads();
+#endif
 #if AV_LSTM_SC1
                 const char* arow = (const char*)Al + (w * 16 + r) * 1024;      // wave w = row tile w, full K (swizzled 1-KiB rows)
 #else
                 const bf16_t* arow = Al + (w * 16 + r) * ALD + 8 * g;          // wave w = row tile w, full K
 #endif
+                if (mbase + w * 16 < B)
 #pragma unroll
                 for (int kk = 0; kk < H / 32; ++kk) {
 #if AV_LSTM_SC1
@@ -217,7 +220,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
                     else store_rest(p, td, row, d, j, c, h, ig, fg, gg, og);
                 }
             }
+#if AV_LSTM_SC1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my LDS reads are done before my next DMA overwrites my rows
+#else
             __syncthreads();                                         // Al is rewritten by the next row group / step
+#endif
         }
         if (s + 1 < T) publish(cnt, tid);
         if (defer) {                                                 // c, gates, out_bt: behind the hand-off, under the next step's wait
@@ -275,8 +282,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
                 // row & 15 on the source side.  Rows >= B read row B-1 (finite) and are never stored.
                 const bf16_t* A = p.dgates + (((long long)tn * B) * 2 + d) * 4 * H;          // row stride 8H
                 const int drow = lane >> 4, dpos = lane & 15;
+                const bool has_rows = mbase + w * 16 < B;             // a row tile past B: nothing staged, nothing multiplied
                 auto dma = [&](int c) {
                     char* buf = (char*)Ab + (c % NRING) * DCH_BYTES;
+                    if (has_rows)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int ii = w * 4 + i, row = ii * 4 + drow;
@@ -289,24 +298,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
                 dma(0); dma(1); dma(2);
 #pragma unroll
                 for (int c = 0; c < NDC; ++c) {
-                    // my 4 instructions of chunk c landed (the 8 of chunks c+1, c+2 may still fly), then everybody's
+                    // my 4 instructions of chunk c landed (the 8 of chunks c+1, c+2 may still fly).  A wavefront stages exactly the 16
+                    // rows of every chunk that its own MFMAs read, so this wait is the whole hand-over: no workgroup barrier in the loop
                     if (c + 2 < NDC) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // chunks c+1, c+2 may still fly
                     else if (c + 1 < NDC) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (c + 3 < NDC) dma(c + 3);                      // ring slot (c+3) % 4 was read in iteration c-1 (barrier above)
+                    if (c + 3 < NDC) dma(c + 3);                      // my rows of ring slot (c+3) % 4 were read in iteration c-1 (lgkmcnt below)
                     const char* arow = (const char*)Ab + (c % NRING) * DCH_BYTES + (w * 16 + r) * 256;
                     const bf16_t* brow = Wt + r * WTLD + c * DCH + 8 * g;
+                    if (has_rows) {
 #pragma unroll
-                    for (int kk = 0; kk < DCH / 32; ++kk) {
-                        const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ (r & 15)) << 4));
-                        const bf16x8 bq = *(const bf16x8*)(brow + kk * 32);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc, 0, 0, 0);
+                        for (int kk = 0; kk < DCH / 32; ++kk) {
+                            const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ (r & 15)) << 4));
+                            const bf16x8 bq = *(const bf16x8*)(brow + kk * 32);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc, 0, 0, 0);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this slot retired before iteration c+1 refills it
                     }
                 }
                 asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_s_barrier();                         // the ring is free for the next row group / step
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -348,28 +358,247 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
     }
 }
 
+// ---- row-split variant (default): grid = 32 unit tiles x 2 directions x NRG row groups (NRG = min(ceil(B / 16), 4)).  Batch rows never
+// interact in the recurrence, so every (direction, row group) is its own chain of 32 workgroups with its own arrival counter (one
+// 128-B line each).  A workgroup owns 16 hidden units x the 16-row tiles rt = z, z + NRG, ...; its W_hh slice lives in REGISTERS
+// (64 VGPRs per lane: wavefront w holds the MFMA B fragments of its quarter of K), so a step stages only the 16 x K operand rows in
+// one shot of wave-private LDS-DMA (forward 4, backward 16 instructions per wavefront, all in flight at once, no ring, no workgroup
+// barrier before the MFMAs), multiplies its K quarter (forward 16, backward 16 MFMAs per wavefront instead of 64) and the four
+// partial tiles meet in LDS; the element-wise tail runs one (row, unit) per thread.  Per-CU traffic per step drops 4x (backward:
+// 64 KiB instead of 256 KiB) and 256 CUs pull instead of 64.  Same arithmetic order inside a K quarter; the cross-quarter sum is
+// ((q0 + q1) + q2) + q3 in fp32 (the 64-row kernel accumulates the same products in one chain: results agree to fp32 rounding).
+constexpr int CNT_STRIDE = 32;               // ints between counters
+constexpr int PSZ = 320;                     // floats of one padded 16 x 16 partial tile
+__device__ __forceinline__ int* group_counter(int* counters, int d, int z) { return counters + CNT_STRIDE * (1 + d * 4 + z); }
+__device__ __forceinline__ int pidx(int row, int unit) { return (row >> 2) * 80 + (row & 3) * 16 + unit; }   // conflict-free for the C layout
+
+__global__ __launch_bounds__(256, 2) void lstm_fwd_split(const PF p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Al = smem;                                                 // [4 wavefronts][16 rows][256 B]: h_{t-1}, K quarter per wavefront
+    float* part = (float*)(smem + 16384);                            // [4 wavefronts][4 gates][PSZ]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int d = blockIdx.y, j0 = blockIdx.x * 16, z = blockIdx.z, nrg = gridDim.z;
+    const int B = p.B, T = p.T, ntile = (B + 15) / 16;
+    const bf16_t* W = p.whh + (long long)d * 4 * H * H;
+    bf16x8 wf[4][4];                                                 // [gate][kk]: B fragments, k = w*128 + kk*32 + 8g .. +7, column = unit j0 + r
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wf[q][kk] = *(const bf16x8*)(W + (long long)(q * H + j0 + r) * H + w * 128 + kk * 32 + 8 * g);
+    int* cnt = group_counter(p.counters, d, z);
+    const int erow = tid >> 4, eu = tid & 15, j = j0 + eu;           // element-wise tail: one (row, unit) per thread
+    const bool defer = z + nrg >= ntile;                             // one row tile per workgroup: stores nobody waits for go behind the hand-off
+    for (int s = 0; s < T; ++s) {
+        const int td = d == 0 ? s : T - 1 - s;
+        const int tp = d == 0 ? td - 1 : td + 1;
+        float pgx[4], pcp;
+        {   // operands that do not depend on other workgroups: loaded BEFORE the wait (first row tile)
+            const int row = z * 16 + erow;
+            const bool ok = row < B;
+            const float* gxr = p.gx + (((long long)td * B + (ok ? row : 0)) * 2 + d) * 4 * H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pgx[q] = ok ? gxr[q * H + j] : 0.f;
+            pcp = (ok && s > 0) ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;             // my own earlier store
+        }
+        if (s > 0) wait_for(cnt, NJT * s, p.counters + 2, tid);      // every unit tile of my (direction, row group) finished step s-1
+        float sv[6];
+        for (int rt = z; rt < ntile; rt += nrg) {
+            if (s > 0) {
+                const bf16_t* hprev = p.hseq + ((long long)tp * B) * 2 * H + d * H;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                        // one instruction = 4 rows x 256 B; the 16-B piece XOR-swizzled with row & 15 on the source side
+                    const int row = 4 * i + g;
+                    const int rr = rt * 16 + row < B ? rt * 16 + row : B - 1;                           // rows >= B: finite duplicates, never stored
+                    const bf16_t* src = hprev + (long long)rr * 2 * H + w * 128 + ((r ^ row) << 3);
+                    const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(w * 4096 + i * 1024));
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Al + off), 16, 0, AV_CPOL_SC0_SC1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                f32x4 acc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const char* arow = Al + w * 4096 + r * 256;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ r) << 4));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[q][kk], acc[q], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part[(w * 4 + q) * PSZ + pidx(4 * g + e, r)] = acc[q][e];
+                __syncthreads();
+            }
+            const int row = rt * 16 + erow;
+            if (row < B) {
+                float gxv[4], cprev;
+                if (rt == z) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gxv[q] = pgx[q];
+                    cprev = pcp;
+                } else {
+                    const float* gxr = p.gx + (((long long)td * B + row) * 2 + d) * 4 * H;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gxv[q] = gxr[q * H + j];
+                    cprev = s > 0 ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;
+                }
+                if (s > 0) {
+                    const int pi = pidx(erow, eu);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        gxv[q] += ((part[q * PSZ + pi] + part[(4 + q) * PSZ + pi]) + part[(8 + q) * PSZ + pi]) + part[(12 + q) * PSZ + pi];
+                }
+                const float ig = sigmoid_fast(gxv[0]);
+                const float fg = sigmoid_fast(gxv[1]);
+                const float gg = tanh_fast(gxv[2]);
+                const float og = sigmoid_fast(gxv[3]);
+                const float c = fg * cprev + ig * gg;
+                const float h = og * tanh_fast(c);
+                store_bf16_pair_coherent(p.hseq + ((long long)td * B + row) * 2 * H + d * H + j, h, eu);       // the only store others wait for
+                if (defer) { sv[0] = c; sv[1] = h; sv[2] = ig; sv[3] = fg; sv[4] = gg; sv[5] = og; }
+                else store_rest(p, td, row, d, j, c, h, ig, fg, gg, og);
+            }
+            if (rt + nrg < ntile) __syncthreads();                   // the partial tiles are rewritten by the next row tile
+        }
+        if (s + 1 < T) publish(cnt, tid);
+        if (defer) {
+            const int row = z * 16 + erow;
+            if (row < B) store_rest(p, td, row, d, j, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void lstm_bwd_split(const PB p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ab = smem;                                                 // [4 wavefronts][16 rows][1024 B]: dgates[t_next], K quarter per wavefront
+    float* part = (float*)(smem + 65536);                            // [4 wavefronts][PSZ]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int d = blockIdx.y, j0 = blockIdx.x * 16, z = blockIdx.z, nrg = gridDim.z;
+    const int B = p.B, T = p.T, ntile = (B + 15) / 16;
+    const bf16_t* W = p.whhT + (long long)d * H * 4 * H;
+    bf16x8 wt[16];                                                   // B fragments of W_hh^T: k = w*512 + kk*32 + 8g .. +7 (gate rows), column = unit j0 + r
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) wt[kk] = *(const bf16x8*)(W + (long long)(j0 + r) * 4 * H + w * 512 + kk * 32 + 8 * g);
+    int* cnt = group_counter(p.counters, d, z);
+    const int erow = tid >> 4, eu = tid & 15, j = j0 + eu;
+    for (int s = 0; s < T; ++s) {
+        const int td = d == 0 ? T - 1 - s : s;
+        const int tn = d == 0 ? td + 1 : td - 1;
+        const int tp = d == 0 ? td - 1 : td + 1;
+        const bool has_prev = d == 0 ? td > 0 : td < T - 1;
+        float pdo, pg[4], pc, pcp, pdc;
+        {   // step-local operands of the first row tile, before the wait
+            const int row = z * 16 + erow;
+            const bool ok = row < B;
+            const int rr = ok ? row : 0;
+            pdo = ok ? ld_any(p.dout, (long long)rr * p.do_bs + (long long)td * p.do_ts + d * H + j, p.dout_dtype) : 0.f;
+            const bf16_t* gs = p.gates + (((long long)td * B + rr) * 2 + d) * 4 * H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pg[q] = ok ? (float)gs[q * H + j] : 0.f;
+            pc = ok ? p.cseq[(((long long)td * B + rr) * 2 + d) * H + j] : 0.f;
+            pcp = (ok && has_prev) ? p.cseq[(((long long)tp * B + rr) * 2 + d) * H + j] : 0.f;
+            pdc = (ok && s > 0) ? p.dc[((long long)d * B + rr) * H + j] : 0.f;                           // my own earlier store
+        }
+        if (s > 0) wait_for(cnt, NJT * s, p.counters + 2, tid);
+        for (int rt = z; rt < ntile; rt += nrg) {
+            if (s > 0) {
+                const bf16_t* A = p.dgates + (((long long)tn * B) * 2 + d) * 4 * H;                      // row stride 8H
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {                       // one instruction = one row's K quarter (1 KiB), piece XOR-swizzled with row & 15
+                    const int rr = rt * 16 + i < B ? rt * 16 + i : B - 1;
+                    const bf16_t* src = A + (long long)rr * 8 * H + w * 512 + ((lane ^ i) << 3);
+                    const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(w * 16384 + i * 1024));
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ab + off), 16, 0, AV_CPOL_SC0_SC1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                const char* arow = Ab + w * 16384 + r * 1024;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ r) << 4));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wt[kk], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[w * PSZ + pidx(4 * g + e, r)] = acc[e];
+                __syncthreads();
+            }
+            const int row = rt * 16 + erow;
+            if (row < B) {
+                float dh, ig, fg, gg, og, c, cprev, dcold;
+                float* dcp = p.dc + ((long long)d * B + row) * H + j;
+                if (rt == z) {
+                    dh = pdo; ig = pg[0]; fg = pg[1]; gg = pg[2]; og = pg[3]; c = pc; cprev = pcp; dcold = pdc;
+                } else {
+                    dh = ld_any(p.dout, (long long)row * p.do_bs + (long long)td * p.do_ts + d * H + j, p.dout_dtype);
+                    const bf16_t* gs = p.gates + (((long long)td * B + row) * 2 + d) * 4 * H;
+                    ig = (float)gs[j]; fg = (float)gs[H + j]; gg = (float)gs[2 * H + j]; og = (float)gs[3 * H + j];
+                    c = p.cseq[(((long long)td * B + row) * 2 + d) * H + j];
+                    cprev = has_prev ? p.cseq[(((long long)tp * B + row) * 2 + d) * H + j] : 0.f;
+                    dcold = s > 0 ? *dcp : 0.f;
+                }
+                if (s > 0) {
+                    const int pi = pidx(erow, eu);
+                    dh += ((part[pi] + part[PSZ + pi]) + part[2 * PSZ + pi]) + part[3 * PSZ + pi];
+                }
+                const float tc = tanh_fast(c);
+                const float dcs = dcold + dh * og * (1.f - tc * tc);
+                *dcp = dcs * fg;
+                bf16_t* dg = p.dgates + (((long long)td * B + row) * 2 + d) * 4 * H;
+                store_bf16_pair_coherent(dg + j, dcs * gg * ig * (1.f - ig), eu);
+                store_bf16_pair_coherent(dg + H + j, dcs * cprev * fg * (1.f - fg), eu);
+                store_bf16_pair_coherent(dg + 2 * H + j, dcs * ig * (1.f - gg * gg), eu);
+                store_bf16_pair_coherent(dg + 3 * H + j, dh * tc * og * (1.f - og), eu);
+            }
+            if (rt + nrg < ntile) __syncthreads();
+        }
+        if (s + 1 < T) publish(cnt, tid);
+    }
+}
+
+constexpr int LDS_FS = 16384 + 16 * PSZ * 4;                       // 36 864
+constexpr int LDS_BS = 65536 + 4 * PSZ * 4;                        // 70 656
+
 constexpr int LDS_F = 64 * WLD * 2 + 64 * ALD * 2;            // 66 560 + 66 560
 constexpr int LDS_B = 16 * WTLD * 2 + NRING * DCH_BYTES;         // 65 792 + 65 536
 
 }  // namespace
 
-// counters: 3 ints of workspace (zeroed here); returns after enqueueing; the timeout flag counters[2] can be read later
+static bool lstm_split_enabled() {
+    static const bool on = [] { const char* e = getenv("AVAMD_LSTM_SPLIT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static int lstm_prepare(void) {
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)lstm_fwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F) != hipSuccess ||
+            hipFuncSetAttribute((const void*)lstm_bwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess ||
+            hipFuncSetAttribute((const void*)lstm_fwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)lstm_bwd_split, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BS) != hipSuccess) {
+            av_set_error("av_lstm_*_layer: cannot raise dynamic LDS"); return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    return AV_OK;
+}
+
+// counters: AV_LSTM_COUNTER_INTS (512) ints of workspace (zeroed here); returns after enqueueing; the timeout flag counters[2] can be read later
 extern "C" int av_lstm_fwd_layer(const float* gx, const void* whh, void* hseq, float* cseq, void* gates, void* out_bt, int* counters,
                                  int T, int B, int Hh, void* stream) {
     AV_CHECK(gx && whh && hseq && cseq && counters, "av_lstm_fwd_layer: null pointer");
     AV_CHECK(Hh == H && T > 0 && B > 0, "av_lstm_fwd_layer: persistent kernel is built for H=512 (got %d), T=%d B=%d", Hh, T, B);
     hipStream_t st = (hipStream_t)stream;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute((const void*)lstm_fwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F) != hipSuccess ||
-            hipFuncSetAttribute((const void*)lstm_bwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess) {
-            av_set_error("av_lstm_*_layer: cannot raise dynamic LDS"); return AV_ERR_LAUNCH;
-        }
-        done = true;
-    }
-    if (hipMemsetAsync(counters, 0, 3 * sizeof(int), st) != hipSuccess) { av_set_error("av_lstm_fwd_layer: memset failed"); return AV_ERR_LAUNCH; }
+    if (lstm_prepare() != AV_OK) return AV_ERR_LAUNCH;
+    if (hipMemsetAsync(counters, 0, AV_LSTM_COUNTER_INTS * sizeof(int), st) != hipSuccess) { av_set_error("av_lstm_fwd_layer: memset failed"); return AV_ERR_LAUNCH; }
     PF p{gx, (const bf16_t*)whh, (bf16_t*)hseq, cseq, (bf16_t*)gates, (bf16_t*)out_bt, counters, T, B};
-    hipLaunchKernelGGL(lstm_fwd_persistent, dim3(NJT, 2), dim3(256), LDS_F, st, p);
+    if (lstm_split_enabled()) {
+        const int ntile = (B + 15) / 16;
+        hipLaunchKernelGGL(lstm_fwd_split, dim3(NJT, 2, ntile < 4 ? ntile : 4), dim3(256), LDS_FS, st, p);
+    } else {
+        hipLaunchKernelGGL(lstm_fwd_persistent, dim3(NJT, 2), dim3(256), LDS_F, st, p);
+    }
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -379,18 +608,15 @@ extern "C" int av_lstm_bwd_layer(const void* dout, int dout_dtype, long long do_
     AV_CHECK(dout && dgates && whhT && gates && cseq && dc && counters, "av_lstm_bwd_layer: null pointer");
     AV_CHECK(Hh == H && T > 0 && B > 0, "av_lstm_bwd_layer: persistent kernel is built for H=512 (got %d), T=%d B=%d", Hh, T, B);
     hipStream_t st = (hipStream_t)stream;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute((const void*)lstm_fwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F) != hipSuccess ||
-            hipFuncSetAttribute((const void*)lstm_bwd_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B) != hipSuccess) {
-            av_set_error("av_lstm_*_layer: cannot raise dynamic LDS"); return AV_ERR_LAUNCH;
-        }
-        done = true;
-    }
-    if (hipMemsetAsync(counters, 0, 3 * sizeof(int), st) != hipSuccess) { av_set_error("av_lstm_bwd_layer: memset failed"); return AV_ERR_LAUNCH; }
+    if (lstm_prepare() != AV_OK) return AV_ERR_LAUNCH;
+    if (hipMemsetAsync(counters, 0, AV_LSTM_COUNTER_INTS * sizeof(int), st) != hipSuccess) { av_set_error("av_lstm_bwd_layer: memset failed"); return AV_ERR_LAUNCH; }
     PB p{dout, dout_dtype, do_bs, do_ts, (bf16_t*)dgates, (const bf16_t*)whhT, (const bf16_t*)gates, cseq, dc, counters, T, B};
-    hipLaunchKernelGGL(lstm_bwd_persistent, dim3(NJT, 2), dim3(256), LDS_B, st, p);
+    if (lstm_split_enabled()) {
+        const int ntile = (B + 15) / 16;
+        hipLaunchKernelGGL(lstm_bwd_split, dim3(NJT, 2, ntile < 4 ? ntile : 4), dim3(256), LDS_BS, st, p);
+    } else {
+        hipLaunchKernelGGL(lstm_bwd_persistent, dim3(NJT, 2), dim3(256), LDS_B, st, p);
+    }
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
-

@@ -51,7 +51,7 @@ def lstm_forward(mod: "CrossAttentionFusion", x_tm: Tensor, save: bool):
             out_bt = torch.empty((B, T, 2 * H), dtype=dtype, device=dev)
         st = ops.stream()
         if PERSISTENT_LSTM and dtype == torch.bfloat16 and H == 512:
-            cnt = torch.empty(3, dtype=torch.int32, device=dev)
+            cnt = torch.empty(L.LSTM_COUNTER_INTS, dtype=torch.int32, device=dev)
             L.check(L.lib().av_lstm_fwd_layer(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates),
                                               ops.ptr(out_bt) if last else None, ops.ptr(cnt), T, B, H, st), "av_lstm_fwd_layer")
             mod._lstm_flags.append(cnt)
@@ -83,7 +83,7 @@ def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: D
         dc = torch.empty((2, B, H), dtype=torch.float32, device=dev)
         st = ops.stream()
         if PERSISTENT_LSTM and dtype == torch.bfloat16 and H == 512:
-            cnt = torch.empty(3, dtype=torch.int32, device=dev)
+            cnt = torch.empty(L.LSTM_COUNTER_INTS, dtype=torch.int32, device=dev)
             L.check(L.lib().av_lstm_bwd_layer(ops.ptr(dout), ops.dt(dout), do_bs, do_ts, ops.ptr(dgates), ops.ptr(whhT), ops.ptr(gates),
                                               ops.ptr(cseq), ops.ptr(dc), ops.ptr(cnt), T, B, H, st), "av_lstm_bwd_layer")
             mod._lstm_flags.append(cnt)

@@ -357,10 +357,11 @@ def test_ctc_greedy_on_device():
     assert bs.greedy_batch(lp.cpu(), 3) == want                                     # host tensors keep the old path
 
 
-@pytest.mark.parametrize("T,B", [(9, 3), (12, 64), (7, 70), (5, 130)])
+@pytest.mark.parametrize("T,B", [(9, 3), (6, 16), (4, 17), (5, 50), (12, 64), (7, 70), (5, 130)])
 def test_persistent_lstm_matches_step_kernels(T, B):
     """lstm_persistent.hip (one launch per layer, coherent hand-off between workgroups, LDS-DMA streaming) against the per-step
-    kernels of lstm.hip on the same buffers: forward h / c / gates, backward dgates / dc; B > 64 exercises the row-group loop."""
+    kernels of lstm.hip on the same buffers: forward h / c / gates, backward dgates / dc; B = 3 .. 50 exercise 1, 2 and 4 row groups
+    with ragged last tiles, B > 64 the row-tile loop inside a workgroup."""
     H = 512
     dt_ = torch.bfloat16
     gx = _rand(T, B, 2, 4 * H)
@@ -372,7 +373,7 @@ def test_persistent_lstm_matches_step_kernels(T, B):
     def run(persistent):
         hseq = torch.zeros(T, B, 2 * H, device="cuda", dtype=dt_); cseq = torch.zeros(T, B, 2, H, device="cuda")
         gates = torch.zeros(T, B, 2, 4 * H, device="cuda", dtype=dt_); dg = torch.zeros_like(gates); dc = torch.zeros(2, B, H, device="cuda")
-        cnt = torch.zeros(3, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(L.LSTM_COUNTER_INTS, dtype=torch.int32, device="cuda")
         if persistent:
             L.check(L.lib().av_lstm_fwd_layer(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates), None, ops.ptr(cnt), T, B, H, st), "fwd")
             L.check(L.lib().av_lstm_bwd_layer(ops.ptr(dout), 0, T * 2 * H, 2 * H, ops.ptr(dg), ops.ptr(whhT), ops.ptr(gates), ops.ptr(cseq), ops.ptr(dc),

@@ -1,15 +1,15 @@
-"""BiLSTM layer timing in isolation (T=100, B=64, H=512, bf16): per-step kernels vs the persistent kernel."""
+"""BiLSTM layer timing in isolation (T=100, B=$LSTM_B (64), H=512, bf16): per-step kernels vs the persistent kernel."""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("multimodal-av-model_amd.ops"); L = importlib.import_module("multimodal-av-model_amd._lib")
-T, B, H = 100, 64, 512
+T, B, H = 100, int(os.environ.get("LSTM_B", "64")), 512
 dt = torch.bfloat16
 gx = torch.randn(T, B, 2, 4 * H, device="cuda")
 whh = (torch.randn(2, 4 * H, H, device="cuda") / 22).to(dt)
 whhT = whh.transpose(1, 2).contiguous()
 hseq = torch.empty(T, B, 2 * H, device="cuda", dtype=dt); cseq = torch.empty(T, B, 2, H, device="cuda")
 gates = torch.empty(T, B, 2, 4 * H, device="cuda", dtype=dt); dg = torch.empty_like(gates); dc = torch.empty(2, B, H, device="cuda")
-dout = torch.randn(B, T, 2 * H, device="cuda"); cnt = torch.empty(3, dtype=torch.int32, device="cuda")
+dout = torch.randn(B, T, 2 * H, device="cuda"); cnt = torch.empty(L.LSTM_COUNTER_INTS, dtype=torch.int32, device="cuda")
 st = ops.stream()
 def steps_f():
     for s in range(T):
