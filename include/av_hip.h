@@ -210,6 +210,15 @@ int av_loss_combine(const float* nll, const float* w, const float* c1, const flo
  * [B][T][V], lengths optional int64 [B] (frames to decode); out_ids int32 [B][T] = collapsed ids padded with -1, out_len int32 [B] */
 int av_ctc_greedy(const float* log_probs, const long long* lengths, int* out_ids, int* out_len, int B, int T, int V, int blank,
                   void* stream);
+/* device side of the input pipeline (dataset/multi_speaker_dataset.py:13-59; decoding wav / npy files stays on the host):
+ * av_lip_gray_resize: src [T][Hs][Ws][C] (uint8 if src_is_u8 else fp32) -> dst fp32 [T][Hd][Wd] = bilinear(mean over C) / divisor
+ *   (:49-58: .astype(float32).mean(-1), cv2.resize INTER_LINEAR law, / 255), float32 operation order of the reference;
+ * av_mix_pair: mixed[i] = (a1[i] + a2[i]) / (max|a1 + a2| + 1e-6) over n = max(len1, len2) samples with zero padding (:21-32),
+ *   mask1 / mask2 int64 [n]: 1 = both speakers, 2 = only this speaker, 0 = otherwise (:35-45); peak_ws: 4 bytes of workspace */
+int av_lip_gray_resize(const void* src, int src_is_u8, float* dst, int T, int Hs, int Ws, int C, int Hd, int Wd, float divisor,
+                       void* stream);
+int av_mix_pair(const float* a1, long long len1, const float* a2, long long len2, float* mixed, long long* mask1, long long* mask2,
+                unsigned* peak_ws, void* stream);
 int av_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, void* stream);
 /* multi-tensor form (one launch per step): ptrs [n_tensors][5] device pointers {param, grad, exp_avg, exp_avg_sq, shadow};

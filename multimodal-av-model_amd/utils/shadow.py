@@ -85,9 +85,14 @@ def lookup_many(params: Sequence[Tensor]) -> List[Optional[Tensor]]:
 
 def mark_fresh(params: Sequence[Tensor]):
     """After the optimizer wrote the shadows of ``params`` (and bumped their versions): the entries are up to date."""
-    seen = set()
+    seen, vals = set(), []
     for p in params:
         hit = _SHADOW.get(id(p))
         if hit is not None and hit[0]() is p and id(hit[2]) not in seen:
             seen.add(id(hit[2]))
             hit[2].refresh()
+            vals.append(hit[2].val)
+    if vals:
+        # the kernel wrote the bf16 tensors through raw pointers: bump their version counters so that caches DERIVED from them
+        # (ops.transpose_cached: W^T for the dX products) rebuild instead of serving last step's weights
+        torch.autograd.graph.increment_version(vals)

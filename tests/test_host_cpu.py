@@ -170,3 +170,37 @@ def test_split_k_heuristic_cpu():
     for tiles in (1, 7, 64, 200, 511):
         s = ops._split_k(tiles, 6368, tiles * 128 * 128)
         assert 1 <= s <= 8 and 6368 // s >= 512
+
+
+def test_checkpoint_round_trip_reference_layout(tmp_path):
+    """checkpoint.py keeps main.py:47-64's dict layout and key sets; the file loads with weights_only=True (no code is unpickled)."""
+    import types
+    init = pkg("utils.init"); enc = pkg("model.encoder"); fm = pkg("model.fusion_module"); dm = pkg("model.decoder"); ck = pkg("checkpoint")
+
+    def make(seed_shift):
+        ve = enc.VisualEncoder(); ve.load_state_dict(init.visual_state_dict(seed=1 + seed_shift))
+        ae = enc.AudioEncoder(dict(init.W2V2_TINY), freeze=True); ae.load_state_dict(init.w2v2_state_dict(init.W2V2_TINY, seed=2 + seed_shift))
+        fu = fm.CrossAttentionFusion(512, 64, 512); fu.load_state_dict(init.fusion_state_dict(512, 64, 512, seed=3 + seed_shift))
+        de = dm.CTCDecoder(1024, 800, 3); de.load_state_dict(init.decoder_state_dict(1024, 800, seed=4 + seed_shift))
+        opt = torch.optim.Adam(list(fu.parameters()) + list(de.parameters()), lr=1e-4)
+        return types.SimpleNamespace(visual_encoder=ve, audio_encoder=ae, fusion_module=fu, decoder1=de, optimizer=opt, device="cpu")
+
+    a, b = make(0), make(10)
+    path = str(tmp_path / "ck.pt")
+    ck.save_checkpoint(7, a, path)
+    raw = torch.load(path, map_location="cpu", weights_only=True)
+    assert tuple(raw) == ck.KEYS and raw["epoch"] == 7
+    assert len(raw["visual_encoder"]) == 129 and len(raw["fusion"]) == 30 and sorted(raw["decoder1"]) == ["net.0.bias", "net.0.weight"]
+    assert set(raw["audio_encoder"]) == set(init.w2v2_state_dict(init.W2V2_TINY))
+    assert ck.load_checkpoint(b, path) == 8
+    for ma, mb in ((a.visual_encoder, b.visual_encoder), (a.fusion_module, b.fusion_module), (a.decoder1, b.decoder1)):
+        for (k, x), (_, y) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert torch.equal(x, y), k
+    assert not torch.equal(a.audio_encoder.state_dict()["model.encoder.layers.0.attention.q_proj.weight"],
+                           b.audio_encoder.state_dict()["model.encoder.layers.0.attention.q_proj.weight"])      # opt-in, as in main.py:60
+    ck.load_checkpoint(b, path, audio_encoder=True, optimizer=True)
+    for (k, x), (_, y) in zip(a.audio_encoder.state_dict().items(), b.audio_encoder.state_dict().items()):
+        assert torch.equal(x, y), k
+    torch.save({"epoch": 1}, path)
+    with pytest.raises(KeyError):
+        ck.load_checkpoint(b, path)

@@ -1,6 +1,8 @@
 """GPU parity of the individual HIP kernels (through the C-ABI) against plain PyTorch fp64/fp32 references."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -391,3 +393,34 @@ def test_persistent_lstm_matches_step_kernels(T, B):
     a, b = run(True), run(False)
     for x, y, name in zip(a, b, ("h", "c", "gates", "dgates", "dc")):
         torch.testing.assert_close(x, y, rtol=3e-2, atol=3e-2, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_device_input_pipeline_equals_numpy_restatement():
+    """csrc/preprocess.hip against oracle/pipeline_oracle.py (the per-sample arithmetic of the reference's load_pair,
+    dataset/multi_speaker_dataset.py:13-59): bit-exact, float32 operation order of the reference.  cv2 is absent from the image, so the
+    resize law itself is pinned only by the oracle's known answers (parity with cv2 unpinned)."""
+    from oracle import pipeline_oracle as po
+    dp = pkg("dataset.device_pipeline"); cf = pkg("dataset.collate_fn").collate_fn
+    rng = np.random.default_rng(11)
+    for shape, dtype in (((7, 128, 128, 3), np.uint8), ((3, 100, 120, 3), np.float32), ((2, 64, 80, 1), np.float32), ((1, 96, 96, 3), np.uint8)):
+        fr = (rng.random(shape) * 255).astype(dtype)
+        got = dp.lips_to_device(fr).cpu().numpy()
+        want = po.lips(fr)
+        assert got.shape == want.shape and np.array_equal(got, want), (shape, float(np.abs(got - want).max()))
+    for n1, n2 in ((1000, 700), (700, 1000), (512, 512), (0, 300), (70001, 64000)):
+        a1 = rng.standard_normal(n1).astype(np.float32); a2 = rng.standard_normal(n2).astype(np.float32)
+        got = dp.mix_pair(a1, a2)
+        mixed, m1, m2 = po.mix_pair(a1, a2)
+        assert np.array_equal(got["audio"].cpu().numpy(), mixed), (n1, n2)
+        assert np.array_equal(got["mask1"].cpu().numpy(), m1) and np.array_equal(got["mask2"].cpu().numpy(), m2)
+    with pytest.raises(RuntimeError):
+        dp.lips_to_device(np.zeros((0, 128, 128, 3), np.uint8))                                  # empty clip: the reference raises too (:59-60)
+    items = []
+    for n1, n2, t1, t2 in ((4000, 3000, 6, 5), (2500, 2500, 4, 4)):
+        items.append(dp.load_pair_device(rng.standard_normal(n1).astype(np.float32), rng.standard_normal(n2).astype(np.float32),
+                                         (rng.random((t1, 128, 128, 3)) * 255).astype(np.uint8), (rng.random((t2, 128, 128, 3)) * 255).astype(np.uint8),
+                                         [5, 6, 7], [8, 9]))
+    batch = cf(items)                                                                             # collate pads device tensors in place
+    assert batch["audio"].is_cuda and batch["audio"].shape == (2, 4000) and batch["lip1"].shape == (2, 6, 1, 96, 96)
+    assert batch["mask1"][1, 2500:].eq(3).all() and batch["mask1"][0, 3000:].eq(2).all() and batch["mask2"][0, 3000:].eq(0).all()
+    assert batch["lip2_lengths"].tolist() == [5, 4] and batch["text1"].tolist() == [[5, 6, 7], [5, 6, 7]]

@@ -209,7 +209,7 @@ def test_avadam_multi_tensor_matches_torch():
 def test_avadam_writes_bf16_shadows_and_keeps_caches_coherent():
     """The fused step writes the bf16 compute copies of the parameters it updates (utils/shadow.py): after a step the cached
     copy equals a fresh cast of the master weights and is NOT rebuilt; an out-of-band update invalidates it."""
-    optim, shadow = pkg("optim"), pkg("utils.shadow")
+    optim, shadow, ops = pkg("optim"), pkg("utils.shadow"), pkg("ops")
     g = torch.Generator().manual_seed(5)
     a = torch.randn(300, 64, generator=g).cuda().requires_grad_(True)
     b = torch.randn(100, 64, generator=g).cuda().requires_grad_(True)
@@ -237,6 +237,8 @@ def test_avadam_writes_bf16_shadows_and_keeps_caches_coherent():
         assert ab.data_ptr() == ab0.data_ptr() and cc.data_ptr() == c0.data_ptr()    # same storage, updated in place
         torch.testing.assert_close(ab, torch.cat([a.data, b.data], 0).to(torch.bfloat16), rtol=0, atol=0)
         torch.testing.assert_close(cc, c.data.to(torch.bfloat16), rtol=0, atol=0)
+        # caches DERIVED from a shadow (W^T for the dX products) must follow the in-place update (the kernel writes through raw pointers)
+        torch.testing.assert_close(ops.transpose_cached(ab), ab.t().contiguous(), rtol=0, atol=0)
     assert builds == ["ab", "c"]                                                     # never rebuilt by the optimizer steps
     with torch.no_grad():
         a.mul_(2.0)                                                                  # out-of-band update: version bump -> rebuild

@@ -63,3 +63,28 @@ def test_oracle_c1_eval_fixture():
         last, mid = O.audio_forward(sds[1], cfg, batch["audio"], batch["mask1"] != 3)
     assert md(last.numpy()[..., ::8], fx["eval_audio_last"]) < 1e-4
     assert md(mid.numpy()[..., ::8], fx["eval_audio_mid"]) < 1e-4
+
+
+def test_pipeline_oracle_known_answers():
+    """oracle/pipeline_oracle.py (load_pair's per-sample arithmetic; cv2 / librosa absent => pinned by known answers only)."""
+    from oracle import pipeline_oracle as po
+    rng = np.random.default_rng(3)
+    img = rng.random((40, 56)).astype(np.float32)
+    assert np.array_equal(po.resize_bilinear(img, 40, 56), img)                                   # identity: every tap lands on a pixel centre
+    ramp = np.tile(np.arange(128, dtype=np.float32), (128, 1))
+    want = (np.arange(96, dtype=np.float64) + 0.5) * (128 / 96) - 0.5                              # a linear image is reproduced exactly by bilinear taps
+    np.testing.assert_allclose(po.resize_bilinear(ramp, 96, 96)[17], want, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(po.resize_bilinear(ramp.T.copy(), 96, 96)[:, 5], want, rtol=0, atol=2e-5)
+    up = po.resize_bilinear(np.array([[0.0, 1.0]], dtype=np.float32), 1, 4)                        # pixel-centre law + clamped borders
+    np.testing.assert_allclose(up[0], [0.0, 0.25, 0.75, 1.0], atol=1e-7)
+    frames = np.full((2, 128, 128, 3), 255, dtype=np.uint8)
+    out = po.lips(frames)
+    assert out.shape == (2, 1, 96, 96) and out.dtype == np.float32 and np.all(out == 1.0)
+    a1 = np.array([0.5, -1.0, 0.25, 0.5, 0.5], dtype=np.float32); a2 = np.array([0.5, -1.0, 0.25], dtype=np.float32)
+    mixed, m1, m2 = po.mix_pair(a1, a2)
+    assert m1.tolist() == [1, 1, 1, 2, 2] and m2.tolist() == [1, 1, 1, 0, 0] and m1.dtype == np.int64
+    np.testing.assert_allclose(mixed, np.array([1.0, -2.0, 0.5, 0.5, 0.5]) / (2.0 + 1e-6), rtol=1e-6)
+    mixed, m1, m2 = po.mix_pair(a2, a1)
+    assert m1.tolist() == [1, 1, 1, 0, 0] and m2.tolist() == [1, 1, 1, 2, 2]
+    mixed, m1, m2 = po.mix_pair(a2, a2)
+    assert m1.tolist() == [1, 1, 1] == m2.tolist()

@@ -148,3 +148,31 @@ def test_host_metadata_gives_the_same_step():
     assert torch.equal(il, md["_ctc_input_lengths"])
     for k in ("loss1", "loss2", "contrast1", "contrast2", "total"):
         assert float(plain[k]) == float(fast[k]), k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_checkpoint_resume_continues_identically(tmp_path, precision):
+    """checkpoint.py (main.py:47-64 layout): a trainer that has diverged (other batches: parameters, Adam moments, BN running
+    statistics, cached bf16 weight shadows all differ) and then loads the checkpoint must take the same next step as the trainer
+    that wrote it."""
+    init = pkg("utils.init"); synth = pkg("dataset.synthetic"); ck = pkg("checkpoint")
+    cfg = init.W2V2_TINY
+    b0 = synth.make_batch(2, 1.0, seed=5, ragged=False); b1 = synth.make_batch(2, 1.0, seed=6, ragged=True)
+    other = synth.make_batch(2, 1.0, seed=9, ragged=False)
+    a = build(cfg, precision)
+    a.train_step(b0)
+    path = str(tmp_path / "resume.pt")
+    ck.save_checkpoint(3, a, path)
+    b = build(cfg, precision)
+    b.train_step(other); b.train_step(other)
+    assert ck.load_checkpoint(b, path, audio_encoder=True, optimizer=True) == 4
+    oa, ob = a.train_step(b1), b.train_step(b1)
+    for k in ("loss1", "loss2", "contrast1", "contrast2", "total"):
+        assert abs(float(oa[k].detach()) - float(ob[k].detach())) <= 1e-6 * max(1.0, abs(float(oa[k].detach()))), k
+    for ma, mb in ((a.visual_encoder, b.visual_encoder), (a.audio_encoder, b.audio_encoder), (a.fusion_module, b.fusion_module), (a.decoder1, b.decoder1)):
+        sa, sb = ma.state_dict(), mb.state_dict()
+        for k in sa:
+            # the key-projection bias has an exactly-zero gradient in exact arithmetic (softmax is shift-invariant per query): its
+            # rounding-noise gradient depends on the atomics' order in the bf16 column sums and Adam turns its sign into +-lr
+            tol = 6e-5 if k.endswith("k_proj.bias") else 2e-5
+            assert maxdiff(sa[k].float().cpu(), sb[k].float().cpu()) < tol, k
