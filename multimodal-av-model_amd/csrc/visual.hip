@@ -53,6 +53,53 @@ __global__ void bn_finalize_kernel(double* __restrict__ ws, double count, const 
     shift[c] = sh;
 }
 
+// train mode, one launch: stage 1 as above, then the LAST workgroup to arrive (ticket counter stored behind the 2C accumulators)
+// finalizes every channel - the accumulators are read back with agent-scope atomic loads (the f64 atomics live in L2) and left
+// zeroed, the counter returns to 0 - so a BatchNorm costs one short launch instead of two.
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __restrict__ part, int nblk, double* __restrict__ ws, double count,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                                                 float* __restrict__ scale, float* __restrict__ shift, int C) {
+    __shared__ double red[4][64];
+    __shared__ int s_last;
+    const int C2 = 2 * C;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * BNR_ROWS;
+    int r1 = r0 + BNR_ROWS;
+    if (r1 > nblk) r1 = nblk;
+    double s = 0.0;
+    if (c < C2)
+        for (int r = r0 + ry; r < r1; r += 4) s += (double)part[(long long)r * C2 + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    unsigned* ticket = (unsigned*)(ws + C2);
+    if (ry == 0) {                                             // wavefront 0 issues the accumulator atomics AND the ticket: in order, and
+        if (c < C2) atomicAdd(ws + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ... acknowledged by L2 before the ticket leaves - no fence (a release
+        if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1;      // fence writes the whole dirty L2 back)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const double sum = __hip_atomic_load(ws + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double sq = __hip_atomic_load(ws + C + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ws[ch] = 0.0; ws[C + ch] = 0.0;                        // zeroed for the next layer (ws_zeroed protocol)
+        const double mean = sum / count;
+        double var = sq / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float sc = gamma[ch] * (float)(1.0 / sqrt(var + (double)eps));
+        scale[ch] = sc;
+        shift[ch] = beta[ch] - (float)mean * sc;
+        if (rmean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
+            rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+        }
+    }
+    if (threadIdx.x == 0) *ticket = 0u;
+}
+
 template <typename T>
 __global__ void bn_act_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                               const T* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
@@ -112,6 +159,7 @@ __global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out,
 }
 
 // ---- bf16 vector forms: one thread = 8 consecutive channels of one pixel (16-B accesses, C % 8 == 0) -------------
+template <bool RES>
 __global__ __launch_bounds__(256) void bn_act_vec_kernel(const bf16x8* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const bf16x8* __restrict__ res,
                                                          const float* __restrict__ rscale, const float* __restrict__ rshift,
@@ -123,23 +171,39 @@ __global__ __launch_bounds__(256) void bn_act_vec_kernel(const bf16x8* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         sc[i] = scale[cg + i]; sh[i] = shift[cg + i];
-        rs[i] = rscale ? rscale[cg + i] : 1.f; rb[i] = rscale ? rshift[cg + i] : 0.f;
+        rs[i] = (RES && rscale) ? rscale[cg + i] : 1.f; rb[i] = (RES && rscale) ? rshift[cg + i] : 0.f;
         sl[i] = slope ? slope[cg + i] : 1.f;
     }
-    for (; e < n8; e += stride) {
-        const bf16x8 xv = x[e];
+    auto apply = [&](const bf16x8& xv, const bf16x8& rv) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (float)xv[i] * sc[i] + sh[i];
-        if (res) {
-            const bf16x8 rv = res[e];
+        if (RES) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += (float)rv[i] * rs[i] + rb[i];
         }
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (bf16_t)(v[i] >= 0.f ? v[i] : v[i] * sl[i]);
-        out[e] = o;
+        return o;
+    };
+    // four independent 16-B loads per operand in flight per thread: one load per iteration leaves a CU with 32 KiB in flight, which
+    // is latency-bound (3.3 TB/s) on the short per-thread loops of the small layers
+    constexpr int U = 4;
+    for (; e < n8; e += U * stride) {
+        bf16x8 xv[U], rv[U];
+        long long idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) idx[u] = e + u * stride < n8 ? e + u * stride : e;        // clamped: unconditional loads, predicated stores
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = x[idx[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rv[u] = RES ? res[idx[u]] : xv[u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bf16x8 o = apply(xv[u], rv[u]);
+            if (u == 0 || e + u * stride < n8) out[e + u * stride] = o;
+        }
     }
 }
 
@@ -196,9 +260,16 @@ __global__ __launch_bounds__(256) void bn_prelu_maxpool_vec_kernel(const bf16x8*
     }
 }
 
-inline int vec_grid(long long n8, int C8) {          // blocks of 256 threads; total threads a multiple of C8 (C8 | 256 here)
+inline int vec_grid(long long n8, int C8, int cap = 2048) {          // blocks of 256 threads; total threads a multiple of C8 (C8 | 256 here)
     long long b = (n8 + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));      // few, long-lived threads: the per-channel parameters are loaded once per thread
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+// BN-apply: few, long-lived threads (2 blocks per CU, 4 x 16 B per operand in flight each).  The per-thread start-up (channel-group
+// index, 40 parameter loads) costs ~12 ns per block: 24 us of a 27 us launch at 2048 blocks on the 59 MB tensors of layer4.  The
+// 9-tap pooling kernel does more work per output and keeps 2048.
+inline int bn_act_cap() {
+    static const int cap = [] { const char* e = getenv("AVAMD_EW_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    return cap;
 }
 
 inline int ew_grid(long long n) {
@@ -215,12 +286,13 @@ extern "C" int av_bn_finalize(const float* partial, int nblk, long long count, c
     AV_CHECK(training ? (partial != nullptr && nblk > 0 && count > 0 && ws != nullptr) : (running_mean && running_var), "av_bn_finalize: missing statistics input");
     hipStream_t st = (hipStream_t)stream;
     if (training) {
-        if (!ws_zeroed && hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { av_set_error("av_bn_finalize: memset failed"); return AV_ERR_LAUNCH; }
-        hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * C + 63) / 64, (nblk + BNR_ROWS - 1) / BNR_ROWS), dim3(256), 0, st, partial, nblk, 2 * C, ws);
-        AV_LAUNCH_CHECK();
+        if (!ws_zeroed && hipMemsetAsync(ws, 0, sizeof(double) * (2 * C + 1), st) != hipSuccess) { av_set_error("av_bn_finalize: memset failed"); return AV_ERR_LAUNCH; }
+        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((2 * C + 63) / 64, (nblk + BNR_ROWS - 1) / BNR_ROWS), dim3(256), 0, st, partial, nblk, ws,
+                           (double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, C);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ws, (double)count, gamma, beta,
+                           running_mean, running_var, momentum, eps, training, scale, shift, C);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ws, (double)count, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, scale, shift, C);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -232,8 +304,10 @@ extern "C" int av_bn_act(const void* x, const float* scale, const float* shift, 
     const bool vec = dtype == AV_BF16 && C % 8 == 0 && 256 % (C / 8) == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
                      (!res || (uintptr_t)res % 16 == 0);
     if (vec)
-        hipLaunchKernelGGL(bn_act_vec_kernel, dim3(vec_grid(n / 8, C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, scale, shift,
-                           (const bf16x8*)res, rscale, rshift, slope, (bf16x8*)out, n / 8, C / 8);
+        if (res) hipLaunchKernelGGL(bn_act_vec_kernel<true>, dim3(vec_grid(n / 8, C / 8, bn_act_cap())), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, scale, shift,
+                                    (const bf16x8*)res, rscale, rshift, slope, (bf16x8*)out, n / 8, C / 8);
+        else hipLaunchKernelGGL(bn_act_vec_kernel<false>, dim3(vec_grid(n / 8, C / 8, bn_act_cap())), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, scale, shift,
+                                (const bf16x8*)res, rscale, rshift, slope, (bf16x8*)out, n / 8, C / 8);
     else if (dtype == AV_F32)
         hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, shift, (const float*)res, rscale, rshift, slope, (float*)out, n, C);
     else
