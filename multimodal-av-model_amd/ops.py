@@ -139,17 +139,29 @@ def transpose(x: Tensor, out_dtype: Optional[torch.dtype] = None, pad_to: int = 
 _WT_CACHE = {}
 
 
-def transpose_cached(b: Tensor) -> Tensor:
-    """W^T of a weight-like operand, cached on (storage, version): frozen layers transpose once, trained ones per step."""
+def transpose_cached(b: Tensor, hot_ok: bool = False) -> Optional[Tensor]:
+    """W^T of a weight-like operand, cached on (storage, version): frozen layers transpose once.  A weight that keeps changing (a
+    trained layer: new version after every optimizer step) is *hot*: with ``hot_ok`` the caller gets None from its third version on and
+    feeds the k-major operand to the GEMM directly instead of paying a transpose pass per step."""
     key = (b.data_ptr(), tuple(b.shape), b.dtype)
     ver = b._version
     hit = _WT_CACHE.get(key)
-    if hit is None or hit[0] != ver or hit[2]() is not b:
+    if hit is None or hit[2]() is not b:
         import weakref
-        hit = (ver, transpose(b), weakref.ref(b))
+        hit = [ver, transpose(b), weakref.ref(b), 0]
         if len(_WT_CACHE) > 512:
             _WT_CACHE.clear()
         _WT_CACHE[key] = hit
+    elif hit[0] != ver:
+        hit[3] += 1
+        if hot_ok and hit[3] >= 2:
+            hit[0], hit[1] = None, None                          # hot: no transposed copy is kept
+            return None
+        hit[0], hit[1] = ver, transpose(b)
+    elif hit[1] is None:
+        if hot_ok:
+            return None
+        hit[0], hit[1] = ver, transpose(b)
     return hit[1]
 
 
@@ -171,10 +183,12 @@ def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, 
     assert b.shape[0] == K and a.is_contiguous() and b.is_contiguous()
     if out is None:
         out = torch.empty(a.shape[:-1] + (N,), dtype=out_dtype or a.dtype, device=a.device)
-    if _fast_ok(a, K, N) and K % 64 == 0 and (b_is_weight or not (KMAJOR and N % 8 == 0)):
-        bt = transpose_cached(b) if b_is_weight else transpose(b)   # [N, K]: K-contiguous operand for the fast kernel
-        gemm(a, bt, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act, aux=aux, R=R, alpha=alpha, drop=drop)
-        return out
+    kmajor_ok = KMAJOR and N % 8 == 0
+    if _fast_ok(a, K, N) and K % 64 == 0 and (b_is_weight or not kmajor_ok):
+        bt = transpose_cached(b, hot_ok=kmajor_ok) if b_is_weight else transpose(b)   # [N, K]: K-contiguous operand for the fast kernel
+        if bt is not None:
+            gemm(a, bt, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act, aux=aux, R=R, alpha=alpha, drop=drop)
+            return out
     # bf16, K % 64 == 0, N % 8 == 0, b not a (cached) weight: the fast kernel reads the k-major B through transposed LDS reads
     gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_mode=L.B_KN, act=act, aux=aux, R=R, alpha=alpha, drop=drop)
     return out

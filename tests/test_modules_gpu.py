@@ -228,6 +228,7 @@ def test_avadam_writes_bf16_shadows_and_keeps_caches_coherent():
     ab0 = cache.get("ab", [a, b], torch.bfloat16, cat_ab, flat=True)
     c0 = cache.get("c", [c], torch.bfloat16, cast_c, flat=True)
     opt = optim.AvAdam([a, b, c], lr=1e-2)
+    abv = ab0.view(200, 128)                                                         # a second weight-like view of the same shadow (shares its version counter)
     for step in range(3):
         for p in (a, c):                                                             # b never has a gradient: its slice stays valid
             p.grad = torch.randn(p.shape, generator=g).cuda()
@@ -239,6 +240,8 @@ def test_avadam_writes_bf16_shadows_and_keeps_caches_coherent():
         torch.testing.assert_close(cc, c.data.to(torch.bfloat16), rtol=0, atol=0)
         # caches DERIVED from a shadow (W^T for the dX products) must follow the in-place update (the kernel writes through raw pointers)
         torch.testing.assert_close(ops.transpose_cached(ab), ab.t().contiguous(), rtol=0, atol=0)
+        hot = ops.transpose_cached(abv, hot_ok=True)             # from its third version on a weight is "hot": no copy, k-major operand instead
+        assert hot is None if step >= 2 else torch.equal(hot, abv.t().contiguous())
     assert builds == ["ab", "c"]                                                     # never rebuilt by the optimizer steps
     with torch.no_grad():
         a.mul_(2.0)                                                                  # out-of-band update: version bump -> rebuild
