@@ -24,6 +24,7 @@ struct FrontP {
     bf16_t* y;           // [B*T][Ho][Wo][64]
     float* stats;        // [tiles][2][64] or null
     int T, H, W, Ho, Wo;
+    int prefetch;
 };
 
 __global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
@@ -51,49 +52,55 @@ __global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
         aoff[ks] = (kt * PH + ky) * PW + 2 * r;                 // + 2*oy_l*PW added per row tile
     }
     const int ntile = p.Ho / TOY;
-    for (int oyt = 0; oyt < ntile; ++oyt) {
-        const int oy0 = oyt * TOY;
-        __syncthreads();                                        // previous tile's image reads are done
-        {   // 4 consecutive patch pixels per thread and iteration; ALL global loads are issued before the first LDS write (a
-            // load -> convert -> write loop pays one memory round trip per iteration)
-            constexpr int NPATCH = KT * PH * (PW / 4), NIT = (NPATCH + 255) / 256;
-            float pv[NIT][4];
-            bool ok[NIT][4];
+    // 4 consecutive patch pixels per thread and iteration.  The loads of tile i+1 are issued right after tile i's patch is in LDS and
+    // stay in flight (20 VGPRs) under tile i's MFMAs, epilogue and stores: their HBM / L2 round trip is off the per-tile critical path.
+    // Loads are unconditional from clamped (always valid) addresses + select afterwards: predicated loads compile to one branch +
+    // vmcnt(0) each, i.e. 20 serial memory round trips per tile.
+    constexpr int NPATCH = KT * PH * (PW / 4), NIT = (NPATCH + 255) / 256;
+    float pv[NIT][4];
+    auto issue_loads = [&](int oy0) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int i = it * 256 + tid;
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            const int pc = i % (PW / 4), q = i / (PW / 4);
+            const int py = q % PH, kt = q / PH;
+            const int ti = t + kt - 2, iy = 2 * oy0 - 3 + py, ix0 = 2 * ox0 - 3 + pc * 4;
+            const int tic = ti < 0 ? 0 : (ti > p.T - 1 ? p.T - 1 : ti), iyc = iy < 0 ? 0 : (iy > p.H - 1 ? p.H - 1 : iy);
+            const float* src = p.x + ((long long)(bt - t + tic) * p.H + iyc) * p.W;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ix = ix0 + e;
+                const int ixc = ix < 0 ? 0 : (ix > p.W - 1 ? p.W - 1 : ix);
+                pv[it][e] = src[ixc];
+            }
+        }
+    };
+    auto write_patch = [&](int oy0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)                              // pin: keeps the loads unconditional and batched
+            asm volatile("" :: "v"(pv[it][0]), "v"(pv[it][1]), "v"(pv[it][2]), "v"(pv[it][3]));
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            if (i < NPATCH) {
                 const int pc = i % (PW / 4), q = i / (PW / 4);
                 const int py = q % PH, kt = q / PH;
                 const int ti = t + kt - 2, iy = 2 * oy0 - 3 + py, ix0 = 2 * ox0 - 3 + pc * 4;
-                const bool rowok = i < NPATCH && ti >= 0 && ti < p.T && iy >= 0 && iy < p.H;
-                // unconditional loads from clamped (always valid) addresses + select: predicated loads compile to one
-                // branch + vmcnt(0) each, i.e. 20 serial memory round trips per tile
-                const int tic = ti < 0 ? 0 : (ti > p.T - 1 ? p.T - 1 : ti), iyc = iy < 0 ? 0 : (iy > p.H - 1 ? p.H - 1 : iy);
-                const float* src = p.x + ((long long)(bt - t + tic) * p.H + iyc) * p.W;
+                const bool rowok = ti >= 0 && ti < p.T && iy >= 0 && iy < p.H;
+                bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ix = ix0 + e;
-                    const int ixc = ix < 0 ? 0 : (ix > p.W - 1 ? p.W - 1 : ix);
-                    pv[it][e] = src[ixc];
-                    ok[it][e] = rowok && ix >= 0 && ix < p.W;
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it)                          // pin: keeps the loads unconditional and batched
-                asm volatile("" :: "v"(pv[it][0]), "v"(pv[it][1]), "v"(pv[it][2]), "v"(pv[it][3]));
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int i = it * 256 + tid;
-                if (i < NPATCH) {
-                    const int pc = i % (PW / 4), q = i / (PW / 4);
-                    const int py = q % PH, kt = q / PH;
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(ok[it][e] ? pv[it][e] : 0.f);
-                    *(bf16x4*)(patch + (kt * PH + py) * PW + pc * 4) = o;
-                }
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((rowok && ix0 + e >= 0 && ix0 + e < p.W) ? pv[it][e] : 0.f);
+                *(bf16x4*)(patch + (kt * PH + py) * PW + pc * 4) = o;
             }
         }
+    };
+    if (p.prefetch) issue_loads(0);
+    for (int oyt = 0; oyt < ntile; ++oyt) {
+        const int oy0 = oyt * TOY;
+        __syncthreads();                                        // previous tile's image reads are done
+        if (!p.prefetch) issue_loads(oy0);
+        write_patch(oy0);
+        if (p.prefetch && oyt + 1 < ntile) issue_loads(oy0 + TOY);
         __syncthreads();
         f32x4 acc[2][4];
 #pragma unroll
@@ -168,7 +175,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
 extern "C" int av_conv3d_front(const float* x, const void* w, void* y, float* stats, int B, int T, int H, int W, void* stream) {
     AV_CHECK(x && w && y && B > 0 && T > 0, "av_conv3d_front: bad args");
     AV_CHECK(H % 16 == 0 && W % 32 == 0, "av_conv3d_front: H=%d must be a multiple of 16 and W=%d of 32", H, W);
-    FrontP p{x, (const bf16_t*)w, (bf16_t*)y, stats, T, H, W, H / 2, W / 2};
+    static const int prefetch = [] { const char* e = getenv("AVAMD_FRONT_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
+    FrontP p{x, (const bf16_t*)w, (bf16_t*)y, stats, T, H, W, H / 2, W / 2, prefetch};
     static bool done = false;
     const int lds = W_BYTES + R2_BYTES;
     if (!done) {
