@@ -97,6 +97,8 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if args.same_device:
         local = 0
+        # rehearsal only: the ranks share ONE GPU, where the persistent BiLSTM kernels of two processes cannot all be resident at once
+        os.environ.setdefault("AVAMD_LSTM_PERSISTENT", "0")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:

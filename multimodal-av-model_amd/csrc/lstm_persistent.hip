@@ -15,7 +15,7 @@ constexpr int H = 512, NJT = H / 16;       // 32 unit tiles per direction
 constexpr int MAXMT = 4;
 constexpr int WLD = H + 8;                 // forward W slice row (bf16 elements): 64 rows x 520
 constexpr int WTLD = 4 * H + 8;            // backward W^T slice row: 16 rows x 2056
-constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr unsigned SPIN_LIMIT = 1u << 18;   // ~1 us per poll: a wait that lasts a quarter of a second is a launch whose workgroups are not all resident
 
 struct PF {
     const float* gx; const bf16_t* whh; bf16_t* hseq; float* cseq; bf16_t* gates; bf16_t* out_bt;

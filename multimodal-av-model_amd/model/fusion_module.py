@@ -223,8 +223,35 @@ class CrossAttentionFusion(nn.Module):
         self.fused_dim, self.num_heads = fused_dim, num_heads
         self._cache = ParamCache()
         self._lstm_flags = []          # arrival/timeout words of the persistent LSTM launches (checked lazily)
+        self._flag_host, self._flag_evt, self._flag_n = None, None, 0
         if fused_dim % 32 or (fused_dim // num_heads) not in (16, 32, 64, 128):
             raise ValueError("fused_dim must be a multiple of 32 with head_dim in {16,32,64,128} for the HIP kernels")
+
+    # ---- timeout words of the persistent BiLSTM launches.  A launch whose workgroups cannot all be resident (a GPU shared with
+    # another process that also runs persistent kernels) gives up after a bounded spin and raises counters[2]; its results are
+    # invalid.  The trainer stages an asynchronous copy of the pending words into pinned memory right before the step's one
+    # synchronising call (F.ctc_loss) and looks at them right after it, so a timeout is reported in the step it happened in
+    # (forward launches) or in the next one (backward launches) without adding a synchronisation.
+    def stage_flag_check(self):
+        if not self._lstm_flags or self._flag_evt is not None:
+            return
+        n = min(len(self._lstm_flags), 16)
+        if self._flag_host is None:
+            self._flag_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+        words = torch.stack([c[2] for c in self._lstm_flags[:n]])
+        self._flag_host[:n].copy_(words, non_blocking=True)
+        self._flag_evt = torch.cuda.Event(); self._flag_evt.record()
+        self._flag_n = n
+        del self._lstm_flags[:n]
+
+    def finish_flag_check(self):
+        if self._flag_evt is None or not self._flag_evt.query():
+            return
+        bad = int(self._flag_host[: self._flag_n].max()) != 0
+        self._flag_evt = None
+        if bad:
+            raise RuntimeError("persistent LSTM kernel: inter-workgroup wait timed out (the step that launched it is invalid); "
+                               "AVAMD_LSTM_PERSISTENT=0 selects the per-step kernels (e.g. on a GPU shared with other processes)")
 
     def cparam(self, p: Tensor, dtype) -> Tensor:
         if dtype == torch.float32:
@@ -245,7 +272,8 @@ class CrossAttentionFusion(nn.Module):
         names = [n for n, p in self._np if p.requires_grad]
         params = [p for n, p in self._np if p.requires_grad]
         save = torch.is_grad_enabled() and (bool(names) or audio_feat.requires_grad or visual_feat.requires_grad)
-        if len(self._lstm_flags) > 64:          # lazy check of old launches' timeout words (they are complete by now)
+        self.finish_flag_check()                # timeout words staged earlier (no synchronisation: pinned copy + event query)
+        if len(self._lstm_flags) > 64:          # nobody staged them (module used outside the trainer): blocking check of the oldest
             old, self._lstm_flags = self._lstm_flags[:32], self._lstm_flags[32:]
             if int(torch.stack(old)[:, 2].max()) != 0:
                 raise RuntimeError("persistent LSTM kernel: inter-workgroup wait timed out (results of that step are invalid)")

@@ -230,8 +230,10 @@ class MultimodalTrainer:
             tl = torch.cat([d["text1_lengths"], d["text2_lengths"]], 0)
             il_h, tl_h = batch.get("_ctc_input_lengths"), batch.get("_ctc_target_lengths")     # host copies: no device sync in ctc_loss
             w_ctc = (0.5 / B) / tl.clamp_min(1).to(torch.float32)        # weights of the per-speaker means (before the CTC call: off the sync)
+            self.fusion_module.stage_flag_check()                  # BiLSTM timeout words -> pinned memory, visible after ctc_loss's own sync
             nll = F.ctc_loss(lp12.transpose(0, 1), tg, il12 if il_h is None else il_h, tl if tl_h is None else tl_h,
                              blank=self.tokenizer.blank_id, reduction="none", zero_infinity=True)
+            self.fusion_module.finish_flag_check()                 # raises if a persistent BiLSTM launch timed out (event query, no sync)
             if nll.is_cuda and nll.dtype == torch.float32 and _FUSED_LOSS:
                 total, l1, l2 = _CombineFn.apply(nll, w_ctc, c1, c2, float(self.lambda_))    # one kernel forward, one backward
             else:

@@ -53,8 +53,14 @@ class GradBucketReducer:
         return views
 
     def wait(self) -> None:
+        import os, time
+        timing = os.environ.get("AVAMD_DP_TIMING") == "1"
         for work, flat, s in self.pending:
+            t0 = time.perf_counter()
             work.wait()
+            if timing:
+                import sys
+                print(f"[dp] bucket {flat.numel() * flat.element_size() / 1e6:8.1f} MB waited {1e3 * (time.perf_counter() - t0):8.1f} ms", file=sys.stderr, flush=True)
             if s is not None:
                 torch.cuda.current_stream(flat.device).wait_stream(s)
         self.pending.clear()
