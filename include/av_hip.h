@@ -182,7 +182,8 @@ int av_conv3d_front(const float* x, const void* w, void* y, float* stats, int B,
 /* bf16 fast path of the 3x3 / stride 1 / pad 1, 64 -> 64 channel convolutions of ResNet-18 layer1 (model/encoder.py:44-57):
  * x bf16 NHWC [n_img][H][W][64], w bf16 [64][9*64] with k = (ky*3+kx)*64 + c, y bf16 [n_img*H*W][64],
  * stats [ceil(n_img*H*W/256)][2][64] BatchNorm partials (optional).  Weights stay in LDS, the input is staged once per filter row. */
-int av_conv3x3_c64(const void* x, const void* w, void* y, float* stats, int n_img, int H, int W, void* stream);
+int av_conv3x3_c64(const void* x, const void* w, void* y, float* stats, int n_img, int H, int W, const float* in_scale,
+                   const float* in_shift, const float* in_slope, void* stream);
 /* ws: 2C + 1 doubles of workspace (2C accumulators + an arrival ticket: train mode is ONE launch, the last workgroup finalizes).
  * ws_zeroed = 1: the caller guarantees ws is zero on entry (the kernel leaves it zero on exit, so one buffer zeroed once serves every
  * BatchNorm of a stream); 0: it is cleared here first. */

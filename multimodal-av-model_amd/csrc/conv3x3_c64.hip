@@ -46,9 +46,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 struct CP {
     const bf16_t* x; const bf16_t* w; bf16_t* y; float* stats;
+    const float* in_scale; const float* in_shift; const float* in_slope;             // XF: per-channel affine + PReLU applied to the input
     int M, H, W, ntiles;
 };
 
+// XF: the input is the RAW output of the previous convolution; its BatchNorm-apply + PReLU (the mid-block activation of a
+// BasicBlock, model/encoder.py:27-31) runs in place on the staged window - one pass over 40 KiB of LDS per 256-pixel tile instead
+// of a 236 MB read + 236 MB write through HBM per convolution.  Same float32 operations as av_bn_act => the same bf16 values.
+template <bool XF>
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Wl = smem;
@@ -70,6 +75,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
     // output pixel m, tap (ky, kx) = m + ky * W + kx)
     const int T = (p.ntiles - (int)blockIdx.x + G - 1) / G;
     const int sub = lane >> 3, choff = ((lane & 7) ^ sub) << 3;
+    float xs[8], xb[8], xl[8];                                                        // XF: parameters of MY channel chunk (fixed per thread:
+    if constexpr (XF) {                                                               // chunk id = k * 256 + tid => slot tid & 7, row & 7 = (tid >> 3) & 7)
+        const int cg = ((tid & 7) ^ ((tid >> 3) & 7)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xs[e] = p.in_scale[cg + e]; xb[e] = p.in_shift[cg + e]; xl[e] = p.in_slope ? p.in_slope[cg + e] : 1.f; }
+    }
     auto stage = [&](int t) {
         const int tile = (int)blockIdx.x + t * G;
         const long long q0 = (long long)tile * CM - (p.W + 1);
@@ -113,6 +124,23 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wg_barrier();
         char* win = Win + (t & 1) * WIN_BYTES;
+        if constexpr (XF) {                                                           // 320 rows x 8 chunks = 10 chunks per thread, in place
+            uint4 tv[NINSTR / 4];
+#pragma unroll
+            for (int k = 0; k < NINSTR / 4; ++k) tv[k] = *(const uint4*)(win + (k * 256 + tid) * 16);
+#pragma unroll
+            for (int k = 0; k < NINSTR / 4; ++k) {
+                const bf16x8 v = __builtin_bit_cast(bf16x8, tv[k]);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e] * xs[e] + xb[e];
+                    o[e] = (bf16_t)(f >= 0.f ? f : f * xl[e]);
+                }
+                *(uint4*)(win + (k * 256 + tid) * 16) = __builtin_bit_cast(uint4, o);
+            }
+            wg_barrier();
+        }
         // 18 steps (ky, kx, k-half), fragments double buffered in registers: the LDS reads of step s+1 are issued before the 16
         // MFMAs of step s (with one wavefront per SIMD nothing else would hide the LDS latency)
         bf16x8 wfA[4], pfA[4], wfB[4], pfB[4];
@@ -213,15 +241,18 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
 
 }  // namespace
 
-extern "C" int av_conv3x3_c64(const void* x, const void* w, void* y, float* stats, int n_img, int H, int W, void* stream) {
+extern "C" int av_conv3x3_c64(const void* x, const void* w, void* y, float* stats, int n_img, int H, int W, const float* in_scale,
+                              const float* in_shift, const float* in_slope, void* stream) {
     AV_CHECK(x && w && y, "av_conv3x3_c64: null pointer");
+    AV_CHECK((in_scale == nullptr) == (in_shift == nullptr) && (in_scale || !in_slope), "av_conv3x3_c64: in_scale / in_shift come together");
     AV_CHECK(n_img > 0 && H > 0 && W > 0 && W <= MAXW && (long long)n_img * H * W < (1ll << 24), "av_conv3x3_c64: bad shape n=%d H=%d W=%d (W <= %d, n*H*W < 2^24)", n_img, H, W, MAXW);
     AV_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0, "av_conv3x3_c64: operands must be 16-byte aligned");
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) {
             ncu = 0;
             av_set_error("av_conv3x3_c64: cannot raise dynamic LDS to %d", LDS_TOTAL);
             return AV_ERR_LAUNCH;
@@ -229,9 +260,11 @@ extern "C" int av_conv3x3_c64(const void* x, const void* w, void* y, float* stat
     }
     CP p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.stats = stats;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.in_slope = in_slope;
     p.M = n_img * H * W; p.H = H; p.W = W; p.ntiles = (p.M + CM - 1) / CM;
     const int G = p.ntiles < ncu ? p.ntiles : ncu;
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(G), dim3(256), LDS_TOTAL, (hipStream_t)stream, p);
+    if (in_scale) hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(G), dim3(256), LDS_TOTAL, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(G), dim3(256), LDS_TOTAL, (hipStream_t)stream, p);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

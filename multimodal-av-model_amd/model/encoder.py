@@ -63,6 +63,7 @@ _TRUNK = ((64, 1), (128, 2), (256, 2), (512, 2))      # (planes, stride of the f
 
 
 FAST_C64 = os.environ.get("AVAMD_CONV_C64", "1") != "0"        # 0: layer1 through the implicit-GEMM kernel (A/B runs)
+FUSE_MID_ACT = os.environ.get("AVAMD_FUSE_MID_ACT", "1") != "0"  # 0: separate BN-apply + PReLU pass between conv1 and conv2 of layer1 (A/B runs)
 
 
 class BasicBlock(nn.Module):
@@ -158,20 +159,29 @@ class VisualEncoder(nn.Module):
             self._nbt.append(bn.num_batches_tracked)        # bumped once per forward with one multi-tensor add (27 tiny launches otherwise)
         return scale, shift
 
-    def _conv2d(self, x, N, H, W, Cin, conv: nn.Module, dtype, training: bool):
+    def _c64_ok(self, conv: nn.Module, dtype, N, H, W, Cin) -> bool:
+        k, st, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        return (dtype == torch.bfloat16 and (k, st, pad, Cin, conv.out_channels) == (3, 1, 1, 64, 64) and W <= 31
+                and N * H * W < (1 << 24) and FAST_C64)
+
+    def _conv2d(self, x, N, H, W, Cin, conv: nn.Module, dtype, training: bool, in_act=None):
+        """``in_act`` = (scale, shift, slope): x is the RAW output of the previous convolution and its BatchNorm-apply + PReLU is
+        applied while the input window is staged (layer1 kernel only: callers check ``_c64_ok``)."""
         k, st = conv.kernel_size[0], conv.stride[0]
         pad = conv.padding[0]
         Cout = conv.out_channels
         Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
         M = N * Ho * Wo
         y = torch.empty((M, Cout), dtype=dtype, device=x.device)
-        if dtype == torch.bfloat16 and (k, st, pad, Cin, Cout) == (3, 1, 1, 64, 64) and W <= 31 and M < (1 << 24) and FAST_C64:
+        if self._c64_ok(conv, dtype, N, H, W, Cin):
             # layer1: weights-stationary kernel (conv3x3_c64.hip), one BN partial per 256 output pixels
             nblk = (M + 255) // 256
             stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device) if training else None
-            L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(self._w(conv, dtype)), ops.ptr(y), ops.ptr(stats), N, H, W, ops.stream()),
-                    "av_conv3x3_c64")
+            isc, ish, isl = in_act if in_act is not None else (None, None, None)
+            L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(self._w(conv, dtype)), ops.ptr(y), ops.ptr(stats), N, H, W,
+                                           ops.ptr(isc), ops.ptr(ish), ops.ptr(isl), ops.stream()), "av_conv3x3_c64")
             return y, stats, nblk, M, Ho, Wo
+        assert in_act is None
         nblk = (M + 127) // 128
         stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device) if training else None
         geo = dict(cT=1, cH=H, cW=W, cCtot=Cin, cCin=Cin, cCoff=0, cKt=1, cKh=k, cKw=k, cSh=st, cSw=st, cPt=0, cPh=pad, cPw=pad,
@@ -228,8 +238,13 @@ class VisualEncoder(nn.Module):
                 slope = blk.relu.weight.data
                 c1, st1, nb1, M1, H1, W1 = self._conv2d(h, N, Hc, Wc, Cc, blk.conv1, dtype, training)
                 s1, b1 = self._bn(blk.bn1, st1, nb1, M1, training)
-                a1 = self._act(c1, s1, b1, slope)
-                c2, st2, nb2, M2, _, _ = self._conv2d(a1, N, H1, W1, blk.conv1.out_channels, blk.conv2, dtype, training)
+                if FUSE_MID_ACT and self._c64_ok(blk.conv2, dtype, N, H1, W1, blk.conv1.out_channels):
+                    # mid-block BN-apply + PReLU inside conv2's window staging: no HBM pass for the activated tensor
+                    c2, st2, nb2, M2, _, _ = self._conv2d(c1, N, H1, W1, blk.conv1.out_channels, blk.conv2, dtype, training,
+                                                          in_act=(s1, b1, slope))
+                else:
+                    a1 = self._act(c1, s1, b1, slope)
+                    c2, st2, nb2, M2, _, _ = self._conv2d(a1, N, H1, W1, blk.conv1.out_channels, blk.conv2, dtype, training)
                 s2, b2 = self._bn(blk.bn2, st2, nb2, M2, training)
                 if blk.downsample is not None:
                     cd, std, nbd, Md, _, _ = self._conv2d(h, N, Hc, Wc, Cc, blk.downsample[0], dtype, training)

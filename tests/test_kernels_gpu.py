@@ -328,7 +328,7 @@ def test_conv3x3_c64_weights_stationary(n_img, H, W):
     y = torch.empty(M, 64, device="cuda", dtype=torch.bfloat16)
     nblk = (M + 255) // 256
     stats = torch.empty(nblk, 2, 64, device="cuda")
-    L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(wk), ops.ptr(y), ops.ptr(stats), n_img, H, W, ops.stream()), "av_conv3x3_c64")
+    L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(wk), ops.ptr(y), ops.ptr(stats), n_img, H, W, None, None, None, ops.stream()), "av_conv3x3_c64")
     ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(M, 64)
     torch.testing.assert_close(y.double(), ref, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(stats[:, 0].sum(0).double(), ref.sum(0), rtol=1e-3, atol=2e-2)
@@ -337,9 +337,18 @@ def test_conv3x3_c64_weights_stationary(n_img, H, W):
     xi = (torch.arange(M * 64, device="cuda").reshape(n_img, H, W, 64) % 5 - 2).to(torch.bfloat16)
     wi = (torch.arange(64 * 576, device="cuda").reshape(64, 64, 3, 3) % 3 - 1).to(torch.bfloat16)
     wki = wi.permute(0, 2, 3, 1).reshape(64, 576).contiguous()
-    L.check(L.lib().av_conv3x3_c64(ops.ptr(xi), ops.ptr(wki), ops.ptr(y), None, n_img, H, W, ops.stream()), "av_conv3x3_c64")
+    L.check(L.lib().av_conv3x3_c64(ops.ptr(xi), ops.ptr(wki), ops.ptr(y), None, n_img, H, W, None, None, None, ops.stream()), "av_conv3x3_c64")
     refi = torch.nn.functional.conv2d(xi.double().permute(0, 3, 1, 2), wi.double(), padding=1).permute(0, 2, 3, 1).reshape(M, 64)
     torch.testing.assert_close(y.double(), refi.to(torch.bfloat16).double(), rtol=0, atol=0)
+    # fused input activation (BatchNorm-apply + PReLU on the staged window) == av_bn_act followed by the plain convolution, bit for bit
+    sc = torch.rand(64, device="cuda") + 0.5; sh = _rand(64); sl = torch.rand(64, device="cuda") * 0.5
+    a = torch.empty_like(x)
+    L.check(L.lib().av_bn_act(ops.ptr(x), ops.ptr(sc), ops.ptr(sh), None, None, None, ops.ptr(sl), ops.ptr(a), 1, x.numel(), 64, ops.stream()), "av_bn_act")
+    y_ref = torch.empty_like(y); y_fused = torch.empty_like(y); st_ref = torch.empty_like(stats); st_fused = torch.empty_like(stats)
+    L.check(L.lib().av_conv3x3_c64(ops.ptr(a), ops.ptr(wk), ops.ptr(y_ref), ops.ptr(st_ref), n_img, H, W, None, None, None, ops.stream()), "av_conv3x3_c64")
+    L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(wk), ops.ptr(y_fused), ops.ptr(st_fused), n_img, H, W, ops.ptr(sc), ops.ptr(sh), ops.ptr(sl),
+                                   ops.stream()), "av_conv3x3_c64")
+    assert torch.equal(y_fused, y_ref) and torch.equal(st_fused, st_ref)
 
 
 def test_ctc_greedy_on_device():

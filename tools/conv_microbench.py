@@ -12,7 +12,7 @@ geo = dict(cT=1, cH=H, cW=W, cCtot=64, cCin=64, cCoff=0, cKt=1, cKh=3, cKw=3, cS
 
 
 def fast():
-    L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(wk), ops.ptr(y), ops.ptr(st1), N, H, W, ops.stream()), "c64")
+    L.check(L.lib().av_conv3x3_c64(ops.ptr(x), ops.ptr(wk), ops.ptr(y), ops.ptr(st1), N, H, W, None, None, None, ops.stream()), "c64")
 
 
 def gemm():
