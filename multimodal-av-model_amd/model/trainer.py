@@ -105,6 +105,11 @@ class MultimodalTrainer:
             self.audio_encoder.model.grad_wait = reducer.wait
             self._head_params = [p for m in (self.decoder1, self.fusion_module) for n, p in m.named_parameters()
                                  if not n.startswith("cross_attn_visual.")]
+            # decoder + fusion gradients are complete when the wav2vec2 backward starts (their AccumulateGrad nodes run with top
+            # priority right after the fusion backward): start their all-reduce there, under the whole audio backward
+            self._head_done = False
+            if pair_batched:                                   # one fusion / decoder call per step: no later accumulation into these grads
+                self.audio_encoder.model.grad_pre = self._reduce_head
 
     # ------------------------------------------------------------------------------------------------------------
     def _to_dev(self, batch):
@@ -256,14 +261,20 @@ class MultimodalTrainer:
         out = self.forward_losses(batch)
         out["total"].backward()
         if self.reducer is not None:
-            # wav2vec2 layer buckets were reduced inside its backward (overlapped); the decoder + fusion bucket goes now
-            hp = [p for p in self._head_params if p.grad is not None]
-            views = self.reducer.reduce_async([p.grad for p in hp])
+            # wav2vec2 layer buckets were reduced inside its backward (overlapped), the decoder + fusion bucket at its start; if that
+            # backward did not run (nothing trainable below the fusion) the bucket goes now
+            if not self._head_done:
+                self._reduce_head()
             self.reducer.wait()
-            for p, v in zip(hp, views):
-                p.grad = v
+            self._head_done = False
         self.optimizer.step()
         return out
+
+    def _reduce_head(self):
+        hp = [p for p in self._head_params if p.grad is not None]
+        for p, v in zip(hp, self.reducer.reduce_async([p.grad for p in hp])):
+            p.grad = v
+        self._head_done = True
 
     def train_epoch(self, dataloader):
         self.visual_encoder.train(); self.audio_encoder.train(); self.fusion_module.train(); self.decoder1.train()

@@ -124,6 +124,7 @@ class Wav2Vec2ModelHIP(nn.Module):
         # data-parallel hooks (parallel/dp.py): per-layer gradient bucket -> async all-reduce, joined at the end of backward
         self.grad_ready = None
         self.grad_wait = None
+        self.grad_pre = None            # called when this model's backward starts (the trainer reduces the head gradients there)
 
     # ---- parameter access ------------------------------------------------------------------------------------
     def P(self, name: str) -> Tensor:
@@ -413,6 +414,8 @@ class _EncodeFn(torch.autograd.Function):
     def backward(fctx, dlast, dmid):
         if fctx.ctx is None:
             return (None, None, None, None) + tuple(None for _ in fctx.names)
+        if fctx.model.grad_pre is not None:
+            fctx.model.grad_pre()
         g = fctx.model.backward(fctx.ctx, dlast, dmid)
         fctx.ctx = None
         return (None, None, None, None) + tuple(g.get(n) for n in fctx.names)

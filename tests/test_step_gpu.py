@@ -176,3 +176,29 @@ def test_checkpoint_resume_continues_identically(tmp_path, precision):
             # rounding-noise gradient depends on the atomics' order in the bf16 column sums and Adam turns its sign into +-lr
             tol = 6e-5 if k.endswith("k_proj.bias") else 2e-5
             assert maxdiff(sa[k].float().cpu(), sb[k].float().cpu()) < tol, k
+
+
+@pytest.mark.parametrize("pair", [True, False])
+def test_bucketed_gradient_path_equals_plain_step(pair):
+    """The data-parallel plumbing at world size 1 (buckets packed into flat buffers, head bucket handed over when the wav2vec2
+    backward starts, Adam reading the bucket views) must be arithmetically invisible: two steps with a reducer == two steps without."""
+    init = pkg("utils.init"); synth = pkg("dataset.synthetic"); dp = pkg("parallel.dp"); tr = pkg("model.trainer")
+    cfg = init.W2V2_TINY
+    batch = synth.make_batch(2, 1.0, seed=5, ragged=True)
+    a = build(cfg, "bf16")
+    b = build(cfg, "bf16")
+    red = dp.GradBucketReducer()
+    assert red.world == 1
+    b2 = tr.MultimodalTrainer(b.visual_encoder, b.audio_encoder, b.fusion_module, b.decoder1, b.tokenizer, learning_rate=1e-4, device="cuda",
+                              lambda_=0.1, reducer=red, pair_batched=pair)
+    b2.fixed_projection = b.fixed_projection
+    a.pair_batched = pair
+    for _ in range(2):
+        oa, ob = a.train_step(batch), b2.train_step(batch)
+        assert abs(float(oa["total"].detach()) - float(ob["total"].detach())) <= 1e-6 * max(1.0, abs(float(oa["total"].detach())))
+    for ma, mb in ((a.audio_encoder, b2.audio_encoder), (a.fusion_module, b2.fusion_module), (a.decoder1, b2.decoder1)):
+        sa, sb = ma.state_dict(), mb.state_dict()
+        for k in sa:
+            tol = 6e-5 if k.endswith("k_proj.bias") else 2e-5
+            assert maxdiff(sa[k].float().cpu(), sb[k].float().cpu()) < tol, k
+    assert (b2.audio_encoder.model.grad_pre is not None) == pair
