@@ -364,6 +364,11 @@ class Wav2Vec2ModelHIP(nn.Module):
                 dh2, grads[p + "final_layer_norm.weight"], grads[p + "final_layer_norm.bias"] = r
             else:
                 dh2 = r
+            if tr and self.grad_ready is not None:                  # first bucket of the layer: the 6 feed-forward tensors (8.4 M of its 12.6 M
+                keys = [k for k in grads if k.startswith(p)]        # parameters) go out while the attention half of the backward runs
+                for k, v in zip(keys, self.grad_ready([grads[k] for k in keys])):
+                    grads[k] = v
+                n_sent = len(keys)
             dh2_t = dh2_lp if dh2_lp is not None else ops.cast_dropout(dh2, dtype, (hd_p, seed, li * 8 + 0))
             Wo = self.c(p + "attention.out_proj.weight", dtype)
             dao = ops.matmul_nn(dh2_t.view(M, Hd), Wo, out_dtype=dtype, b_is_weight=True).view(B, T, nh, hd)
@@ -392,8 +397,8 @@ class Wav2Vec2ModelHIP(nn.Module):
             else:
                 dh = r
             ctx["saved"][li] = None        # free as we go
-            if tr and self.grad_ready is not None:                  # bucket = this layer's 16 tensors, reduced on a side stream
-                keys = [k for k in grads if k.startswith(p)]
+            if tr and self.grad_ready is not None:                  # second bucket: the layer's 10 attention / layer-norm tensors (dicts keep
+                keys = [k for k in grads if k.startswith(p)][n_sent:]   # insertion order: the first n_sent keys are already on their way)
                 for k, v in zip(keys, self.grad_ready([grads[k] for k in keys])):
                     grads[k] = v
         if self.grad_wait is not None:
