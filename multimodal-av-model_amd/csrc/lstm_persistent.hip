@@ -570,6 +570,20 @@ static bool lstm_split_enabled() {
     static const bool on = [] { const char* e = getenv("AVAMD_LSTM_SPLIT"); return !(e && e[0] == '0'); }();
     return on;
 }
+// row groups that can be co-resident: every workgroup of the launch spins on its peers, so the whole grid (64 x row groups) must fit
+// on the device at two workgroups per CU (a partitioned GPU exposes fewer CUs)
+static int lstm_row_groups(int B) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    const int ntile = (B + 15) / 16;
+    int nrg = ntile < 4 ? ntile : 4;
+    while (nrg > 1 && 2 * NJT * nrg > 2 * ncu) --nrg;
+    return 2 * NJT * nrg <= 2 * ncu ? nrg : 0;
+}
+
 static int lstm_prepare(void) {
     static bool done = false;
     if (!done) {
@@ -593,9 +607,10 @@ extern "C" int av_lstm_fwd_layer(const float* gx, const void* whh, void* hseq, f
     if (lstm_prepare() != AV_OK) return AV_ERR_LAUNCH;
     if (hipMemsetAsync(counters, 0, AV_LSTM_COUNTER_INTS * sizeof(int), st) != hipSuccess) { av_set_error("av_lstm_fwd_layer: memset failed"); return AV_ERR_LAUNCH; }
     PF p{gx, (const bf16_t*)whh, (bf16_t*)hseq, cseq, (bf16_t*)gates, (bf16_t*)out_bt, counters, T, B};
+    const int nrg = lstm_row_groups(B);
+    AV_CHECK(nrg > 0, "av_lstm_fwd_layer: the persistent kernel needs 32 compute units (use the step kernels)");
     if (lstm_split_enabled()) {
-        const int ntile = (B + 15) / 16;
-        hipLaunchKernelGGL(lstm_fwd_split, dim3(NJT, 2, ntile < 4 ? ntile : 4), dim3(256), LDS_FS, st, p);
+        hipLaunchKernelGGL(lstm_fwd_split, dim3(NJT, 2, nrg), dim3(256), LDS_FS, st, p);
     } else {
         hipLaunchKernelGGL(lstm_fwd_persistent, dim3(NJT, 2), dim3(256), LDS_F, st, p);
     }
@@ -611,9 +626,10 @@ extern "C" int av_lstm_bwd_layer(const void* dout, int dout_dtype, long long do_
     if (lstm_prepare() != AV_OK) return AV_ERR_LAUNCH;
     if (hipMemsetAsync(counters, 0, AV_LSTM_COUNTER_INTS * sizeof(int), st) != hipSuccess) { av_set_error("av_lstm_bwd_layer: memset failed"); return AV_ERR_LAUNCH; }
     PB p{dout, dout_dtype, do_bs, do_ts, (bf16_t*)dgates, (const bf16_t*)whhT, (const bf16_t*)gates, cseq, dc, counters, T, B};
+    const int nrg = lstm_row_groups(B);
+    AV_CHECK(nrg > 0, "av_lstm_bwd_layer: the persistent kernel needs 32 compute units (use the step kernels)");
     if (lstm_split_enabled()) {
-        const int ntile = (B + 15) / 16;
-        hipLaunchKernelGGL(lstm_bwd_split, dim3(NJT, 2, ntile < 4 ? ntile : 4), dim3(256), LDS_BS, st, p);
+        hipLaunchKernelGGL(lstm_bwd_split, dim3(NJT, 2, nrg), dim3(256), LDS_BS, st, p);
     } else {
         hipLaunchKernelGGL(lstm_bwd_persistent, dim3(NJT, 2), dim3(256), LDS_B, st, p);
     }
