@@ -201,7 +201,7 @@ def main():
                 traffic = round(tb / tl) if tl else None
             n = len(probe["records"])
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_kernel<128,false,false,false> + gemm_nt_bf16_v2_kernel (K >= 2048)" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>") + " (all nn.Linear-form products: forward, dX, dW, strided conv1d)",
+            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_kernel<128,false,false,false> + gemm_nt_bf16_v2_kernel (K >= 2048)" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>") + " (row-major NT products: every nn.Linear forward, dX through cached W^T, strided conv1d; the k-major dW / trained-layer dX launches run a sibling instantiation and are not in this figure)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_note": "HBM-side bytes per launch from profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
                     "algorithmic_bytes_per_launch": round(tot_by / n),
