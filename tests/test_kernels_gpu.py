@@ -368,7 +368,7 @@ def test_ctc_greedy_on_device():
     assert bs.greedy_batch(lp.cpu(), 3) == want                                     # host tensors keep the old path
 
 
-@pytest.mark.parametrize("T,B", [(1, 1), (9, 3), (6, 16), (4, 17), (5, 50), (12, 64), (7, 70), (5, 130), (3, 200)])
+@pytest.mark.parametrize("T,B", [(1, 1), (9, 3), (6, 16), (4, 17), (5, 50), (12, 64), (100, 64), (7, 70), (5, 130), (3, 200)])
 def test_persistent_lstm_matches_step_kernels(T, B):
     """lstm_persistent.hip (one launch per layer, coherent hand-off between workgroups, LDS-DMA streaming) against the per-step
     kernels of lstm.hip on the same buffers: forward h / c / gates, backward dgates / dc; B = 3 .. 50 exercise 1, 2 and 4 row groups
