@@ -619,6 +619,159 @@ __global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v3 (EXPERIMENTAL, off by default; AVAMD_GEMM_V3=1 for N >= 2048, =2 for every NT product): 256 x 256 x 32 tile, 8 wavefronts as 2 (M) x 4 (N) with 128 x 64 each (128 accumulator
+// registers): 12 fragment reads per 32 MFMAs instead of 16, and half the L2->LDS bytes per flop of the 128 x 128 tile.  FOUR LDS
+// stages of 32 KiB (A 256 x 32 + B 256 x 32 bf16; rows are 64 B, so a 16-row fragment block is one contiguous KiB: no swizzle
+// needed), three K-steps of LDS-DMA in flight, counted vmcnt + ONE raw barrier per K-step, fragments of step t+1 read under the
+// MFMAs of step t.  Epilogue in two 128-row halves through the (freed) ring.  Correct (the GEMM tests pass with it switched on) but
+// not faster yet: 1.10 PF/s at 8192^3 (128 x 128 kernel: 1.15-1.22, hipBLASLt's 256 x 256 stream-K kernel: 1.55), 637-680 TF/s on
+// 6368 x 4096 x 1024 (400 tiles on 256 CUs = 1.56 rounds).  It is the starting point for the stream-K kernel of DESIGN.md section 7.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int V3_BM = 256, V3_BN = 256, V3_BK = 32, V3_NT = 512;
+constexpr int V3_STAGE = (V3_BM + V3_BN) * V3_BK * 2;       // 32 768 B
+constexpr int V3_CLD = V3_BN + 4;
+constexpr int V3_EPI = 128 * V3_CLD * 4;                    // 133 120 B
+constexpr int V3_LDS = 4 * V3_STAGE > V3_EPI ? 4 * V3_STAGE : V3_EPI;
+
+// rows [row0 + 32 w, +32) of a K-contiguous operand, k in [k0, k0 + 32): two wave instructions of 16 rows x 64 B (lane = row * 4 + chunk)
+__device__ __forceinline__ void v3_stage_rows(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (w * 2 + i) * 16 + (lane >> 2);
+        int gr = row0 + row;
+        if (gr > nrows - 1) gr = nrows - 1;                      // clamped rows are computed but never stored
+        const bf16_t* src = base + (long long)gr * ld + k0 + ((lane & 3) << 3);
+        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 2 + i) * 1024));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
+    const int wrow = (w >> 2) * 128, wcol = (w & 3) * 64;
+    const int r = lane & 15, g = lane >> 4;
+    const int nwg = nbM * nbN;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * nbN;
+    const int grp = bid / per_group, in_grp = bid - grp * per_group;
+    const int first_m = grp * GM;
+    const int gsz = nbM - first_m < GM ? nbM - first_m : GM;
+    const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
+    const int m0 = mb * V3_BM, n0 = nb * V3_BN;
+    const int z = blockIdx.z;
+    const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
+    const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
+    const bf16_t* A = (const bf16_t*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
+    const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int kt, char* buf) {                                   // 4 LDS-DMA instructions per wavefront and stage
+        v3_stage_rows(A, p.lda, m0, p.M, kt * V3_BK, buf, w, lane);
+        v3_stage_rows(B, p.ldb, n0, p.N, kt * V3_BK, buf + V3_BM * V3_BK * 2, w, lane);
+    };
+    const int nk = p.K / V3_BK;
+    stage(0, smem);
+    if (nk > 1) stage(1, smem + V3_STAGE);
+    if (nk > 2) stage(2, smem + 2 * V3_STAGE);
+
+    const int a_off = (wrow + r) * 64 + g * 16, b_off = V3_BM * V3_BK * 2 + (wcol + r) * 64 + g * 16;
+    // stage 0 landed for everyone; its B fragments and first two A fragments go to registers
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 b[4], bn[4], a[3], ap[2];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) b[jj] = *(const bf16x8*)(smem + b_off + jj * 1024);
+    ap[0] = *(const bf16x8*)(smem + a_off);
+    ap[1] = *(const bf16x8*)(smem + a_off + 1024);
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sa = smem + (kt & 3) * V3_STAGE + a_off;
+        a[0] = ap[0]; a[1] = ap[1];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {                                    // first half of the K-step: A fragments two m-tiles ahead
+            a[(ii + 2) % 3] = *(const bf16x8*)(sa + (ii + 2) * 1024);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ii % 3], b[jj], acc[ii][jj], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            // hand-over of stage kt+1 in the MIDDLE of the MFMA block (16 MFMAs are queued behind it): my LDS-DMA of stage kt+1 landed
+            // (stage kt+2 may fly), barrier, then stage kt+3 goes into the slot of stage kt-1 and the first fragments of stage kt+1
+            // are read under the second half of this K-step
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 3 < nk) stage(kt + 3, smem + ((kt + 3) & 3) * V3_STAGE);
+            const char* nb_ = smem + ((kt + 1) & 3) * V3_STAGE;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) bn[jj] = *(const bf16x8*)(nb_ + b_off + jj * 1024);
+            ap[0] = *(const bf16x8*)(nb_ + a_off);
+            ap[1] = *(const bf16x8*)(nb_ + a_off + 1024);
+        }
+#pragma unroll
+        for (int ii = 4; ii < 8; ++ii) {
+            if (ii + 2 < 8) a[(ii + 2) % 3] = *(const bf16x8*)(sa + (ii + 2) * 1024);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ii % 3], b[jj], acc[ii][jj], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) b[jj] = bn[jj];
+    }
+
+    float* cs = (float*)smem;
+    const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
+    const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
+    const float* bias = p.bias ? p.bias + (long long)zi * p.sBias : nullptr;
+    constexpr int CPR = V3_BN / 8;                                          // 32 chunks of 8 columns per row
+    float bv[8];
+    {
+        const int gnt = n0 + (tid % CPR) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (bias && gnt + e < p.N) ? bias[gnt + e] : 0.f;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                                    // ring / previous half's image is free
+        if ((w >> 2) == half) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        cs[(i * 16 + 4 * g + e) * V3_CLD + wcol + j * 16 + r] = acc[i][j][e] * p.alpha;
+        }
+        __syncthreads();
+        for (int it = 0; it < 128 * CPR / V3_NT; ++it) {
+            const int id = it * V3_NT + tid;
+            const int row = id / CPR, cc = (id % CPR) * 8;
+            const int gm = m0 + half * 128 + row, gn = n0 + cc;
+            if (gm >= p.M || gn >= p.N) continue;
+            float v[8];
+            const f32x4 v0 = *(const f32x4*)(cs + row * V3_CLD + cc), v1 = *(const f32x4*)(cs + row * V3_CLD + cc + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
+            const bool full = gn + 8 <= p.N;
+            const long long off = cbase + (long long)gm * p.ldc + gn;
+            epilogue_store(p, fl, v, off, gm, gn, full, R);
+        }
+    }
+}
+
 template <int BNT, bool CONV, bool AKM = false, bool BKM = false>
 int launch_fast(const av_gemm_args& p, hipStream_t st, const FastFlags& fl) {
     constexpr int STAGE = TILE_A + BNT * BK * 2;
@@ -670,6 +823,21 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         if (akm && bkm) return launch_fast<128, false, true, true>(p, st, fl);
         if (akm) return launch_fast<128, false, true, false>(p, st, fl);
         return launch_fast<128, false, false, true>(p, st, fl);
+    }
+    static const int v3_mode = [] { const char* e = getenv("AVAMD_GEMM_V3"); return e ? atoi(e) : 0; }();   // experimental 256 x 256 kernel: 0 never, 1 when N >= 2048
+    if (!conv && !narrow && v3_mode > 0 && p.M >= 512 && p.N >= (v3_mode == 1 ? 2048 : 256) && p.K % V3_BK == 0) {
+        static bool v3_attr = false;
+        if (!v3_attr) {
+            if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS) != hipSuccess) {
+                av_set_error("av_gemm(fast v3): cannot raise dynamic LDS to %d", V3_LDS);
+                return AV_ERR_LAUNCH;
+            }
+            v3_attr = true;
+        }
+        const int nbM = av_cdiv(p.M, V3_BM), nbN = av_cdiv(p.N, V3_BN);
+        hipLaunchKernelGGL(gemm_nt_bf16_v3_kernel, dim3((unsigned)(nbM * (long long)nbN), 1, (unsigned)p.batch), dim3(V3_NT), V3_LDS, st, p, nbM, nbN, fl);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
     }
     static const int v2_mode = [] { const char* e = getenv("AVAMD_GEMM_V2"); return e ? atoi(e) : 2; }();   // 0 never, 1 always, 2 (default) when K >= 2048
     if (!conv && !narrow && p.M >= 512 && (v2_mode == 1 || (v2_mode == 2 && p.K >= 2048))) {
