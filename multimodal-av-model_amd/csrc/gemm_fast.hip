@@ -620,32 +620,24 @@ __global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v3 (EXPERIMENTAL, off by default; AVAMD_GEMM_V3=1 for N >= 2048, =2 for every NT product): 256 x 256 x 32 tile, 8 wavefronts as 2 (M) x 4 (N) with 128 x 64 each (128 accumulator
-// registers): 12 fragment reads per 32 MFMAs instead of 16, and half the L2->LDS bytes per flop of the 128 x 128 tile.  FOUR LDS
-// stages of 32 KiB (A 256 x 32 + B 256 x 32 bf16; rows are 64 B, so a 16-row fragment block is one contiguous KiB: no swizzle
-// needed), three K-steps of LDS-DMA in flight, counted vmcnt + ONE raw barrier per K-step, fragments of step t+1 read under the
-// MFMAs of step t.  Epilogue in two 128-row halves through the (freed) ring.  Correct (the GEMM tests pass with it switched on) but
-// not faster yet: 1.10 PF/s at 8192^3 (128 x 128 kernel: 1.15-1.22, hipBLASLt's 256 x 256 stream-K kernel: 1.55), 637-680 TF/s on
-// 6368 x 4096 x 1024 (400 tiles on 256 CUs = 1.56 rounds).  It is the starting point for the stream-K kernel of DESIGN.md section 7.
+// v3 (EXPERIMENTAL, off by default; AVAMD_GEMM_V3=1 for N >= 2048, =2 for every NT product): 256 x 256 x 64 tile, 8 wavefronts
+// as 2 (M) x 4 (N) with 128 x 64 each (128 accumulator registers), two LDS stages of 64 KiB.
+// Measured (8192^3, random operands): this form 1.18 PF/s; the same tile with BK = 32, 64-B rows and a FOUR-stage ring (three K-steps
+// in flight) 1.09-1.10 PF/s whatever the barrier structure (plain, stage hand-over in the middle of the MFMA block with the next
+// fragments read under its second half, two wavefront groups staggered by half a K-step, s_setprio around the MFMAs: all within
+// 1 %); the 128 x 128 kernel 1.15-1.22, the vendor library's 256 x 256 stream-K kernel 1.55.  Reading: a 64-B row costs a full line
+// request on the LDS-DMA path (lines per MAC: 128 x 128 x 64 -> 1, 256 x 128 x 64 -> 0.75, 256 x 256 x 64 -> 0.5, 256 x 256 x 32 -> 1),
+// so rows stay 128 B; with 64 KiB per stage only ONE K-step can be in flight in 160 KiB of LDS, and a K-step then costs about its
+// 2048 MFMA clocks PLUS the tail of its DMA (64 KiB at ~32 B/clk is also ~2048 clocks, issued after the barrier): ~52 % MFMA
+// utilisation, as measured.  The missing piece is half-tile granularity (8 x 16 KiB slots, three half-tiles always in flight, one
+// C quadrant per phase: guide section 5), not the tile shape.  On 6368 x 4096 x 1024 (400 tiles on 256 CUs) it equals the 128 x 128
+// kernel (74 us), so it is not dispatched by default; with stream-K it is the candidate for the wide K = 1024 products.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int V3_BM = 256, V3_BN = 256, V3_BK = 32, V3_NT = 512;
-constexpr int V3_STAGE = (V3_BM + V3_BN) * V3_BK * 2;       // 32 768 B
+constexpr int V3_BM = 256, V3_BN = 256, V3_NT = 512;
+constexpr int V3_STAGE = (V3_BM + V3_BN) * BK * 2;          // 65 536 B
 constexpr int V3_CLD = V3_BN + 4;
 constexpr int V3_EPI = 128 * V3_CLD * 4;                    // 133 120 B
-constexpr int V3_LDS = 4 * V3_STAGE > V3_EPI ? 4 * V3_STAGE : V3_EPI;
-
-// rows [row0 + 32 w, +32) of a K-contiguous operand, k in [k0, k0 + 32): two wave instructions of 16 rows x 64 B (lane = row * 4 + chunk)
-__device__ __forceinline__ void v3_stage_rows(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile, int w, int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (w * 2 + i) * 16 + (lane >> 2);
-        int gr = row0 + row;
-        if (gr > nrows - 1) gr = nrows - 1;                      // clamped rows are computed but never stored
-        const bf16_t* src = base + (long long)gr * ld + k0 + ((lane & 3) << 3);
-        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 2 + i) * 1024));
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
-    }
-}
+constexpr int V3_LDS = 2 * V3_STAGE > V3_EPI ? 2 * V3_STAGE : V3_EPI;
 
 __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -677,59 +669,37 @@ __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](int kt, char* buf) {                                   // 4 LDS-DMA instructions per wavefront and stage
-        v3_stage_rows(A, p.lda, m0, p.M, kt * V3_BK, buf, w, lane);
-        v3_stage_rows(B, p.ldb, n0, p.N, kt * V3_BK, buf + V3_BM * V3_BK * 2, w, lane);
+    auto stage = [&](int kt, char* buf) {                                   // 8 LDS-DMA instructions per wavefront and stage (8 rows x 128 B each)
+        stage_rows<4>(A, p.lda, m0, p.M, kt * BK, buf, w, lane);
+        stage_rows<4>(B, p.ldb, n0, p.N, kt * BK, buf + V3_BM * BK * 2, w, lane);
     };
-    const int nk = p.K / V3_BK;
+    const int nk = p.K / BK;
     stage(0, smem);
-    if (nk > 1) stage(1, smem + V3_STAGE);
-    if (nk > 2) stage(2, smem + 2 * V3_STAGE);
-
-    const int a_off = (wrow + r) * 64 + g * 16, b_off = V3_BM * V3_BK * 2 + (wcol + r) * 64 + g * 16;
-    // stage 0 landed for everyone; its B fragments and first two A fragments go to registers
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    bf16x8 b[4], bn[4], a[3], ap[2];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) b[jj] = *(const bf16x8*)(smem + b_off + jj * 1024);
-    ap[0] = *(const bf16x8*)(smem + a_off);
-    ap[1] = *(const bf16x8*)(smem + a_off + 1024);
+    const int sw = r & 7;
+    const int a_off = (wrow + r) * 128, b_off = V3_BM * BK * 2 + (wcol + r) * 128;
     for (int kt = 0; kt < nk; ++kt) {
-        const char* sa = smem + (kt & 3) * V3_STAGE + a_off;
-        a[0] = ap[0]; a[1] = ap[1];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // my LDS-DMA of stage kt landed ...
+        __builtin_amdgcn_s_barrier();                                       // ... everyone's; every wavefront is done reading stage kt-1
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * V3_STAGE);   // in flight under the 64 MFMAs of this K-step
+        const char* sa = smem + (kt & 1) * V3_STAGE + a_off;
+        const char* sb = smem + (kt & 1) * V3_STAGE + b_off;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {                                    // first half of the K-step: A fragments two m-tiles ahead
-            a[(ii + 2) % 3] = *(const bf16x8*)(sa + (ii + 2) * 1024);
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 4 + g) ^ sw) << 4;
+            bf16x8 b[4], a[3];                                               // A fragments two m-tiles ahead of their MFMAs
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ii % 3], b[jj], acc[ii][jj], 0, 0, 0);
+            for (int jj = 0; jj < 4; ++jj) b[jj] = *(const bf16x8*)(sb + jj * 2048 + ch);
+            a[0] = *(const bf16x8*)(sa + ch);
+            a[1] = *(const bf16x8*)(sa + 2048 + ch);
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                if (ii + 2 < 8) a[(ii + 2) % 3] = *(const bf16x8*)(sa + (ii + 2) * 2048 + ch);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ii % 3], b[jj], acc[ii][jj], 0, 0, 0);
+            }
         }
-        if (kt + 1 < nk) {
-            // hand-over of stage kt+1 in the MIDDLE of the MFMA block (16 MFMAs are queued behind it): my LDS-DMA of stage kt+1 landed
-            // (stage kt+2 may fly), barrier, then stage kt+3 goes into the slot of stage kt-1 and the first fragments of stage kt+1
-            // are read under the second half of this K-step
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + 3 < nk) stage(kt + 3, smem + ((kt + 3) & 3) * V3_STAGE);
-            const char* nb_ = smem + ((kt + 1) & 3) * V3_STAGE;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) bn[jj] = *(const bf16x8*)(nb_ + b_off + jj * 1024);
-            ap[0] = *(const bf16x8*)(nb_ + a_off);
-            ap[1] = *(const bf16x8*)(nb_ + a_off + 1024);
-        }
-#pragma unroll
-        for (int ii = 4; ii < 8; ++ii) {
-            if (ii + 2 < 8) a[(ii + 2) % 3] = *(const bf16x8*)(sa + (ii + 2) * 1024);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ii % 3], b[jj], acc[ii][jj], 0, 0, 0);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) b[jj] = bn[jj];
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): my reads of stage kt are complete before the next barrier
     }
 
     float* cs = (float*)smem;
@@ -824,8 +794,8 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         if (akm) return launch_fast<128, false, true, false>(p, st, fl);
         return launch_fast<128, false, false, true>(p, st, fl);
     }
-    static const int v3_mode = [] { const char* e = getenv("AVAMD_GEMM_V3"); return e ? atoi(e) : 0; }();   // experimental 256 x 256 kernel: 0 never, 1 when N >= 2048
-    if (!conv && !narrow && v3_mode > 0 && p.M >= 512 && p.N >= (v3_mode == 1 ? 2048 : 256) && p.K % V3_BK == 0) {
+    static const int v3_mode = [] { const char* e = getenv("AVAMD_GEMM_V3"); return e ? atoi(e) : 0; }();   // experimental 256 x 256 kernel: 0 never, 1 when N >= 2048, 2 for every NT product
+    if (!conv && !narrow && v3_mode > 0 && p.M >= 512 && p.N >= (v3_mode == 1 ? 2048 : 256)) {
         static bool v3_attr = false;
         if (!v3_attr) {
             if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS) != hipSuccess) {
