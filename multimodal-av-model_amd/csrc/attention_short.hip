@@ -159,6 +159,107 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short_kernel(const AttnP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- forward, T > 256
+// Same register-resident-P scheme, keys streamed through LDS in chunks of 128 with an online softmax: a workgroup owns 128 queries
+// (8 wavefronts x 16) of one (batch, head); per chunk a wavefront computes S^T (8 tiles), folds the chunk maximum into its running
+// maximum, rescales its running sum and O^T by 2^(m_old - m_new) and adds the chunk's P V.  (config 3: T_enc = 749.)
+template <bool DROP>
+__global__ __launch_bounds__(NT, 4) void attn_fwd_long_kernel(const AttnP p) {
+    constexpr int NKP = 4, KC = 32 * NKP;                      // 128 keys per chunk (256 would need 64 S registers: spills at 4 waves per SIMD)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = (bf16_t*)smem;
+    bf16_t* Vs = Ks + KC * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+    const bf16_t* Q = (const bf16_t*)p.q + (long long)b * p.q_bs + (long long)h * 64;
+    const bf16_t* K = (const bf16_t*)p.k + (long long)b * p.k_bs + (long long)h * 64;
+    const bf16_t* V = (const bf16_t*)p.v + (long long)b * p.v_bs + (long long)h * 64;
+    const float c = p.scale * LOG2E;
+    const int qt = blockIdx.z * NW + w;                         // my 16-query tile (wave-uniform)
+    const bool active = qt * 16 < p.Tq;
+    const int qrow = qt * 16 + r;
+    const bf16_t* qp = Q + (long long)(qrow < p.Tq ? qrow : p.Tq - 1) * p.q_rs + 8 * g;
+    const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 O[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) O[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nchunk = (klen + KC - 1) / KC;                    // chunks past klen hold only masked keys
+    for (int kc = 0; kc < nchunk; ++kc) {
+        const int k0 = kc * KC;
+        __syncthreads();                                        // every wavefront is done with the previous chunk
+        stage_img(Ks, K + (long long)k0 * p.k_rs, p.k_rs, p.Tk - k0 < KC ? p.Tk - k0 : KC, KC, tid);
+        stage_img(Vs, V + (long long)k0 * p.v_rs, p.v_rs, p.Tk - k0 < KC ? p.Tk - k0 : KC, KC, tid);
+        __syncthreads();
+        if (!active) continue;                                  // wave-uniform
+        asm volatile("" ::: "memory");
+        f32x4 S[2 * NKP];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; ++t) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            a = mfma(row_frag(Ks, 16 * t + r, g), qf0, a);
+            a = mfma(row_frag(Ks, 16 * t + r, 4 + g), qf1, a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = (k0 + 16 * t + 4 * g + e) < klen ? a[e] * c : -INFINITY;
+                mx = fmaxf(mx, a[e]);
+            }
+            S[t] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                   // finite: the first chunk holds key 0 < klen
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(S[t][e] - m_new);
+                sum += pv;
+                S[t][e] = pv;
+            }
+        if (DROP) {
+            const float ik = 1.0f / (1.0f - p.drop_p);
+            const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * p.Tk + k0;
+#pragma unroll
+            for (int t = 0; t < 2 * NKP; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[t][e] *= drop_mult_call(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g + e), p.drop_p, ik);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) O[n][e] *= alpha;
+#pragma unroll
+        for (int tp = 0; tp < NKP; ++tp) {
+            const bf16x8 pf = pack8(S[2 * tp], S[2 * tp + 1]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) O[n] = mfma(tr_frag(Vs, 32 * tp, n, lane), pf, O[n]);
+        }
+    }
+    if (active && qrow < p.Tq) {
+        const float inv = 1.0f / l_run;
+        bf16_t* o = (bf16_t*)p.o + (long long)b * p.o_bs + (long long)qrow * p.o_rs + (long long)h * 64 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            bf16x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(O[n][e] * inv);
+            *(bf16x4*)(o + 16 * n) = ov;
+        }
+        if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Tq + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- backward
 template <bool DROP>
 __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int R) {
@@ -367,8 +468,29 @@ int launch_bwd_short(const BwdP& p, int R, int lds, hipStream_t st) {
 
 }  // namespace
 
+template <bool DROP>
+int launch_fwd_long(const AttnP& p, hipStream_t st) {
+    const int lds = 2 * 128 * 64 * 2;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)attn_fwd_long_kernel<DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            av_set_error("av_attention_fwd: cannot raise dynamic LDS to %d", lds);
+            return AV_ERR_LAUNCH;
+        }
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_long_kernel<DROP>), dim3((unsigned)p.H, (unsigned)p.B, (unsigned)((p.Tq + 16 * NW - 1) / (16 * NW))), dim3(NT), lds, st, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
 int av_attention_short_fwd_try(const AttnP& p, int D, hipStream_t st) {
-    if (D != 64 || p.Tk > 256 || p.Tq > 256 || !p.vec_ok || !short_enabled() || !al8(p.o, p.o_bs, p.o_rs) || p.B > 65535) return AV_SHORT_NOT_TAKEN;
+    if (D != 64 || !p.vec_ok || !short_enabled() || !al8(p.o, p.o_bs, p.o_rs) || p.B > 65535) return AV_SHORT_NOT_TAKEN;
+    if (p.Tk > 256 || p.Tq > 256) {
+        static const bool long_on = [] { const char* e = getenv("AVAMD_ATTN_LONG"); return !(e && e[0] == '0'); }();
+        if (!long_on || (p.Tq + 16 * NW - 1) / (16 * NW) > 65535) return AV_SHORT_NOT_TAKEN;
+        return p.drop_p > 0.f ? launch_fwd_long<true>(p, st) : launch_fwd_long<false>(p, st);
+    }
     switch ((p.Tk + 31) / 32) {
         case 1: return launch_fwd_short<1>(p, st);
         case 2: return launch_fwd_short<2>(p, st);

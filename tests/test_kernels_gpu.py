@@ -194,7 +194,9 @@ def test_log_softmax_colsum_cast():
                                                 (2, 4, 25, 25, 128, False), (1, 2, 300, 300, 64, True), (2, 3, 70, 130, 32, True),
                                                 # D = 64, T <= 256 (bf16): whole-sequence kernels of attention_short.hip
                                                 (2, 4, 49, 49, 64, True), (2, 2, 256, 256, 64, True), (1, 3, 130, 130, 64, False),
-                                                (2, 2, 70, 130, 64, True), (2, 2, 130, 70, 64, True), (1, 1, 1, 1, 64, False)])
+                                                (2, 2, 70, 130, 64, True), (2, 2, 130, 70, 64, True), (1, 1, 1, 1, 64, False),
+                                                # D = 64, T > 256 (bf16): chunked forward with an online softmax (config 3: T_enc = 749)
+                                                (2, 3, 749, 749, 64, True), (1, 2, 130, 600, 64, False), (1, 2, 257, 257, 64, True)])
 def test_attention_fwd_bwd(dtype, B, H, Tq, Tk, D, masked):
     packed = Tq == Tk
     if packed:
