@@ -420,6 +420,200 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- backward, T > 256
+// The two phases of the kernel above as two launches with the OTHER operand streamed through LDS in chunks of 128 rows:
+//   kv kernel: a workgroup owns 128 keys (a wavefront 16: K / V fragments and the dK^T / dV^T accumulators stay in registers), the
+//              queries (Q, dO images, delta, LSE) arrive chunk by chunk;
+//   q kernel:  a workgroup owns 128 queries (a wavefront 16: Q / dO fragments, delta, LSE, dQ^T in registers), K and V arrive in chunks.
+constexpr int LC = 128;                          // rows per streamed chunk
+
+template <bool DROP>
+__global__ __launch_bounds__(NT, 4) void attn_bwd_long_kv_kernel(const BwdP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* I0 = (bf16_t*)smem;                 // Q chunk image
+    bf16_t* I1 = I0 + LC * 64;                  // dO chunk image
+    float* lse_s = (float*)(I1 + LC * 64);
+    float* del_s = lse_s + LC;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+    const bf16_t* Q = p.q + (long long)b * p.q_bs + (long long)h * 64;
+    const bf16_t* K = p.k + (long long)b * p.k_bs + (long long)h * 64;
+    const bf16_t* V = p.v + (long long)b * p.v_bs + (long long)h * 64;
+    const bf16_t* O = p.o + (long long)b * p.o_bs + (long long)h * 64;
+    const bf16_t* DO = p.dout + (long long)b * p.do_bs + (long long)h * 64;
+    const float* lse = p.lse + ((long long)b * p.H + h) * p.Tq;
+    const float c = p.scale * LOG2E;
+    const float ik = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const unsigned long long dbase = ((unsigned long long)b * p.H + h) * p.Tq;
+    const int kt = blockIdx.z * NW + w;                         // my 16-key tile (wave-uniform)
+    const bool active = kt * 16 < p.Tk;
+    const int krow = kt * 16 + r;
+    const long long kld = krow < p.Tk ? krow : p.Tk - 1;
+    const bf16x8 kf0 = *(const bf16x8*)(K + kld * p.k_rs + 8 * g), kf1 = *(const bf16x8*)(K + kld * p.k_rs + 32 + 8 * g);
+    const bf16x8 vf0 = *(const bf16x8*)(V + kld * p.v_rs + 8 * g), vf1 = *(const bf16x8*)(V + kld * p.v_rs + 32 + 8 * g);
+    const bool kok = krow < klen;
+    f32x4 dVt[4], dKt[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { dVt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int q0 = 0; q0 < p.Tq; q0 += LC) {
+        const int nv = p.Tq - q0 < LC ? p.Tq - q0 : LC;
+        __syncthreads();                                        // every wavefront is done with the previous chunk
+        stage_img(I0, Q + (long long)q0 * p.q_rs, p.q_rs, nv, LC, tid);
+        {   // dO image + delta: 8 consecutive lanes share a row; unconditional loads from clamped rows, select afterwards
+            bf16x8 dvv[2], ovv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c0 = tid + u * NT, row = c0 >> 3, ch = c0 & 7;
+                const long long rr = q0 + (row < nv ? row : nv - 1);
+                dvv[u] = *(const bf16x8*)(DO + rr * p.do_rs + ch * 8);
+                ovv[u] = *(const bf16x8*)(O + rr * p.o_rs + ch * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c0 = tid + u * NT, row = c0 >> 3, ch = c0 & 7;
+                const bool ok = row < nv;
+                float sacc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sacc += (float)dvv[u][e] * (float)ovv[u][e];
+                sacc = ok ? sacc : 0.f;
+                *(bf16x8*)(I1 + swz(row, ch)) = ok ? dvv[u] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                sacc += __shfl_xor(sacc, 1, 64); sacc += __shfl_xor(sacc, 2, 64); sacc += __shfl_xor(sacc, 4, 64);
+                if (ch == 0) del_s[row] = sacc;
+            }
+        }
+        if (tid < LC) lse_s[tid] = tid < nv ? lse[q0 + tid] * LOG2E : 0.f;
+        __syncthreads();
+        if (!active) continue;                                  // wave-uniform
+        asm volatile("" ::: "memory");
+        for (int qp = 0; qp < LC / 32; ++qp) {
+            if (32 * qp >= nv) break;                            // wave-uniform
+            f32x4 Pt[2], St[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int ql = 32 * qp + 16 * hf;
+                f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                sv = mfma(row_frag(I0, ql + r, g), kf0, sv);
+                sv = mfma(row_frag(I0, ql + r, 4 + g), kf1, sv);
+                dp = mfma(row_frag(I1, ql + r, g), vf0, dp);
+                dp = mfma(row_frag(I1, ql + r, 4 + g), vf1, dp);
+                const f32x4 l4 = *(const f32x4*)(lse_s + ql + 4 * g), d4 = *(const f32x4*)(del_s + ql + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = q0 + ql + 4 * g + e;
+                    const float pv = (kok && q < p.Tq) ? __builtin_amdgcn_exp2f(sv[e] * c - l4[e]) : 0.f;
+                    float dm = 1.f;
+                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + q) * p.Tk + krow, p.drop_p, ik);
+                    Pt[hf][e] = pv * dm;
+                    St[hf][e] = pv * (dp[e] * dm - d4[e]) * p.scale;
+                }
+            }
+            const bf16x8 pf = pack8(Pt[0], Pt[1]), sf = pack8(St[0], St[1]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                dVt[n] = mfma(tr_frag(I1, 32 * qp, n, lane), pf, dVt[n]);
+                dKt[n] = mfma(tr_frag(I0, 32 * qp, n, lane), sf, dKt[n]);
+            }
+        }
+    }
+    if (active && krow < p.Tk) {
+        bf16_t* ok = p.dk + (long long)b * p.dk_bs + (long long)krow * p.dk_rs + (long long)h * 64 + 4 * g;
+        bf16_t* ov = p.dv + (long long)b * p.dv_bs + (long long)krow * p.dv_rs + (long long)h * 64 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            bf16x4 a, c4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = (bf16_t)dKt[n][e]; c4[e] = (bf16_t)dVt[n][e]; }
+            *(bf16x4*)(ok + 16 * n) = a;
+            *(bf16x4*)(ov + 16 * n) = c4;
+        }
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(NT, 4) void attn_bwd_long_q_kernel(const BwdP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* I0 = (bf16_t*)smem;                 // K chunk image
+    bf16_t* I1 = I0 + LC * 64;                  // V chunk image
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+    const bf16_t* Q = p.q + (long long)b * p.q_bs + (long long)h * 64;
+    const bf16_t* K = p.k + (long long)b * p.k_bs + (long long)h * 64;
+    const bf16_t* V = p.v + (long long)b * p.v_bs + (long long)h * 64;
+    const bf16_t* O = p.o + (long long)b * p.o_bs + (long long)h * 64;
+    const bf16_t* DO = p.dout + (long long)b * p.do_bs + (long long)h * 64;
+    const float* lse = p.lse + ((long long)b * p.H + h) * p.Tq;
+    const float c = p.scale * LOG2E;
+    const float ik = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const unsigned long long dbase = ((unsigned long long)b * p.H + h) * p.Tq;
+    const int qt = blockIdx.z * NW + w;
+    const bool active = qt * 16 < p.Tq;
+    const int qrow = qt * 16 + r;
+    const long long qld = qrow < p.Tq ? qrow : p.Tq - 1;
+    const bf16x8 qf0 = *(const bf16x8*)(Q + qld * p.q_rs + 8 * g), qf1 = *(const bf16x8*)(Q + qld * p.q_rs + 32 + 8 * g);
+    const bf16x8 of0 = *(const bf16x8*)(DO + qld * p.do_rs + 8 * g), of1 = *(const bf16x8*)(DO + qld * p.do_rs + 32 + 8 * g);
+    const bf16x8 oo0 = *(const bf16x8*)(O + qld * p.o_rs + 8 * g), oo1 = *(const bf16x8*)(O + qld * p.o_rs + 32 + 8 * g);
+    float dq_ = 0.f;                                            // delta = sum_d dO o O of my query: 16 of the 64 d on this lane
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq_ += (float)of0[e] * (float)oo0[e] + (float)of1[e] * (float)oo1[e];
+    dq_ += __shfl_xor(dq_, 16, 64);
+    dq_ += __shfl_xor(dq_, 32, 64);
+    const bool qok = qrow < p.Tq;
+    const float lq = lse[qld] * LOG2E;
+    f32x4 dQt[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dQt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kend = klen;                                      // keys >= klen contribute nothing
+    for (int k0 = 0; k0 < kend; k0 += LC) {
+        const int nv = p.Tk - k0 < LC ? p.Tk - k0 : LC;
+        __syncthreads();
+        stage_img(I0, K + (long long)k0 * p.k_rs, p.k_rs, nv, LC, tid);
+        stage_img(I1, V + (long long)k0 * p.v_rs, p.v_rs, nv, LC, tid);
+        __syncthreads();
+        if (!active) continue;
+        asm volatile("" ::: "memory");
+        for (int tp = 0; tp < LC / 32; ++tp) {
+            if (k0 + 32 * tp >= kend) break;                     // wave-uniform
+            f32x4 St[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int kl = 32 * tp + 16 * hf;
+                f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                sv = mfma(row_frag(I0, kl + r, g), qf0, sv);
+                sv = mfma(row_frag(I0, kl + r, 4 + g), qf1, sv);
+                dp = mfma(row_frag(I1, kl + r, g), of0, dp);
+                dp = mfma(row_frag(I1, kl + r, 4 + g), of1, dp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + kl + 4 * g + e;
+                    const float pv = (qok && key < klen) ? __builtin_amdgcn_exp2f(sv[e] * c - lq) : 0.f;
+                    float dm = 1.f;
+                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + qrow) * p.Tk + key, p.drop_p, ik);
+                    St[hf][e] = pv * (dp[e] * dm - dq_) * p.scale;
+                }
+            }
+            const bf16x8 sf = pack8(St[0], St[1]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) dQt[n] = mfma(tr_frag(I0, 32 * tp, n, lane), sf, dQt[n]);
+        }
+    }
+    if (active && qok) {
+        bf16_t* oq = p.dq + (long long)b * p.dq_bs + (long long)qrow * p.dq_rs + (long long)h * 64 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            bf16x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (bf16_t)dQt[n][e];
+            *(bf16x4*)(oq + 16 * n) = a;
+        }
+    }
+}
+
 bool short_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -503,10 +697,25 @@ int av_attention_short_fwd_try(const AttnP& p, int D, hipStream_t st) {
     }
 }
 
+template <bool DROP>
+int launch_bwd_long(const BwdP& p, hipStream_t st) {
+    const int lds = 2 * LC * 64 * 2 + 2 * LC * 4;
+    const unsigned zk = (unsigned)((p.Tk + 16 * NW - 1) / (16 * NW)), zq = (unsigned)((p.Tq + 16 * NW - 1) / (16 * NW));
+    hipLaunchKernelGGL(attn_bwd_long_kv_kernel<DROP>, dim3((unsigned)p.H, (unsigned)p.B, zk), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL(attn_bwd_long_q_kernel<DROP>, dim3((unsigned)p.H, (unsigned)p.B, zq), dim3(NT), 2 * LC * 64 * 2, st, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
 int av_attention_short_bwd_try(const BwdP& p, int D, hipStream_t st) {
-    if (D != 64 || p.Tk > 256 || p.Tq > 256 || !p.vec_ok || !short_enabled() || p.B > 65535 || !al8(p.dq, p.dq_bs, p.dq_rs) ||
+    if (D != 64 || !p.vec_ok || !short_enabled() || p.B > 65535 || !al8(p.dq, p.dq_bs, p.dq_rs) ||
         !al8(p.dk, p.dk_bs, p.dk_rs) || !al8(p.dv, p.dv_bs, p.dv_rs))
         return AV_SHORT_NOT_TAKEN;
+    if (p.Tk > 256 || p.Tq > 256) {
+        static const bool long_on = [] { const char* e = getenv("AVAMD_ATTN_LONG"); return !(e && e[0] == '0'); }();
+        if (!long_on || !p.o || !p.lse || (p.Tq + 16 * NW - 1) / (16 * NW) > 65535 || (p.Tk + 16 * NW - 1) / (16 * NW) > 65535) return AV_SHORT_NOT_TAKEN;
+        return p.drop_p > 0.f ? launch_bwd_long<true>(p, st) : launch_bwd_long<false>(p, st);
+    }
     const int tmax = p.Tq > p.Tk ? p.Tq : p.Tk;
     const int R = (tmax + 31) / 32 * 32;
     const int lds = 2 * R * 64 * 2 + 2 * R * 4;
