@@ -49,7 +49,7 @@ def test_gemm_epilogue_dropout_matches_mask(dtype):
     torch.testing.assert_close(out, ref, **tol)
 
 
-@pytest.mark.parametrize("B,H,T,D", [(2, 4, 70, 64), (1, 2, 130, 128)])
+@pytest.mark.parametrize("B,H,T,D", [(2, 4, 70, 64), (1, 2, 130, 128), (1, 2, 300, 64)])      # 300: the chunked T > 256 kernels with dropout
 def test_attention_dropout_fwd_bwd_same_mask(B, H, T, D):
     ops = pkg("ops")
     dtype = torch.bfloat16
