@@ -639,6 +639,16 @@ constexpr int V3_CLD = V3_BN + 4;
 constexpr int V3_EPI = 128 * V3_CLD * 4;                    // 133 120 B
 constexpr int V3_LDS = 2 * V3_STAGE > V3_EPI ? 2 * V3_STAGE : V3_EPI;
 
+// one LDS-DMA wave instruction of a 256-row operand tile: rows 8 ins .. 8 ins + 7 (128 B each, chunk XOR-swizzled with the row)
+__device__ __forceinline__ void v3_stage_one(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile, int ins, int lane) {
+    const int sub = lane >> 3, pch = lane & 7;
+    int gr = row0 + ins * 8 + sub;
+    if (gr > nrows - 1) gr = nrows - 1;
+    const bf16_t* src = base + (long long)gr * ld + k0 + ((pch ^ sub) << 3);
+    const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(ins * 1024));
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+}
+
 __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
@@ -677,11 +687,25 @@ __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm
     stage(0, smem);
     const int sw = r & 7;
     const int a_off = (wrow + r) * 128, b_off = V3_BM * BK * 2 + (wcol + r) * 128;
+#ifdef AV_V3_STAMPS                                                       // diagnostic build (tools/v3_stamps.cpp): core-clock stamps per loop phase
+    unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_mma = 0;
+#define V3_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime();
+#else
+#define V3_STAMP(x)
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+        V3_STAMP(ts0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // my LDS-DMA of stage kt landed ...
+        V3_STAMP(ts1)
         __builtin_amdgcn_s_barrier();                                       // ... everyone's; every wavefront is done reading stage kt-1
         asm volatile("" ::: "memory");
-        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * V3_STAGE);   // in flight under the 64 MFMAs of this K-step
+        V3_STAMP(ts2)
+        // the 8 LDS-DMA instructions of stage kt+1 are NOT issued here in one burst: measured with core-clock stamps
+        // (tools/v3_stamps.cpp), a burst right after the barrier holds every wavefront for 600-1300 clocks (64 instructions x 8
+        // lines queue at the CU's address unit) while the MFMA pipes idle; they go out one per m-tile group of the first K-half below
+        const bool more = kt + 1 < nk;
+        char* nbuf = smem + ((kt + 1) & 1) * V3_STAGE;
+        V3_STAMP(ts3)
         const char* sa = smem + (kt & 1) * V3_STAGE + a_off;
         const char* sb = smem + (kt & 1) * V3_STAGE + b_off;
 #pragma unroll
@@ -697,10 +721,26 @@ __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm
                 if (ii + 2 < 8) a[(ii + 2) % 3] = *(const bf16x8*)(sa + (ii + 2) * 2048 + ch);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ii % 3], b[jj], acc[ii][jj], 0, 0, 0);
+                if (ks == 0 && more) {                                       // one LDS-DMA instruction of stage kt+1 behind every 4 MFMAs
+                    if (ii < 4) v3_stage_one(A, p.lda, m0, p.M, (kt + 1) * BK, nbuf, w * 4 + ii, lane);
+                    else v3_stage_one(B, p.ldb, n0, p.N, (kt + 1) * BK, nbuf + V3_BM * BK * 2, w * 4 + ii - 4, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): my reads of stage kt are complete before the next barrier
+#ifdef AV_V3_STAMPS
+        V3_STAMP(ts4)
+        st_wait += ts1 - ts0; st_bar += ts2 - ts1; st_issue += ts3 - ts2; st_mma += ts4 - ts3;
+#endif
     }
+#ifdef AV_V3_STAMPS
+    if (lane == 0 && (w == 0 || w == 5) && p.aux) {                         // [2 wavefronts][5]: wait, barrier, DMA issue, reads + MFMA issue, K-tiles
+        unsigned long long* d = (unsigned long long*)p.aux + (w == 0 ? 0 : 5);
+        atomicAdd(d + 0, st_wait); atomicAdd(d + 1, st_bar); atomicAdd(d + 2, st_issue); atomicAdd(d + 3, st_mma); atomicAdd(d + 4, (unsigned long long)nk);
+    }
+#endif
+#undef V3_STAMP
 
     float* cs = (float*)smem;
     const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
