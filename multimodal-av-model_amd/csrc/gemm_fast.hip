@@ -43,6 +43,17 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, long
 }
 
 
+// ONE LDS-DMA wave instruction of an operand tile (for kernels that spread a stage's instructions over their MFMA groups): rows 8 ins .. 8 ins + 7 (128 B each, chunk XOR-swizzled with the row)
+__device__ __forceinline__ void stage_one(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile, int ins, int lane) {
+    const int sub = lane >> 3, pch = lane & 7;
+    int gr = row0 + ins * 8 + sub;
+    if (gr > nrows - 1) gr = nrows - 1;
+    const bf16_t* src = base + (long long)gr * ld + k0 + ((pch ^ sub) << 3);
+    const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(ins * 1024));
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+}
+
+
 // ---- k-major operands (element (k, c) at base[k * ld + c]: the A of dW = dY^T X, the B of dX = dY W) --------------------
 // Tile = 64 k-rows x 128 columns (256-B rows), filled by LDS-DMA (a wave instruction = 4 rows); MFMA fragments come out of it
 // with ds_read_b64_tr_b16: a 16-lane group reads 4 k-rows x 16 columns and receives them column-major, so lane (c = lane & 15,
@@ -639,16 +650,6 @@ constexpr int V3_CLD = V3_BN + 4;
 constexpr int V3_EPI = 128 * V3_CLD * 4;                    // 133 120 B
 constexpr int V3_LDS = 2 * V3_STAGE > V3_EPI ? 2 * V3_STAGE : V3_EPI;
 
-// one LDS-DMA wave instruction of a 256-row operand tile: rows 8 ins .. 8 ins + 7 (128 B each, chunk XOR-swizzled with the row)
-__device__ __forceinline__ void v3_stage_one(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile, int ins, int lane) {
-    const int sub = lane >> 3, pch = lane & 7;
-    int gr = row0 + ins * 8 + sub;
-    if (gr > nrows - 1) gr = nrows - 1;
-    const bf16_t* src = base + (long long)gr * ld + k0 + ((pch ^ sub) << 3);
-    const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(ins * 1024));
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
-}
-
 __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
@@ -722,8 +723,8 @@ __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ii % 3], b[jj], acc[ii][jj], 0, 0, 0);
                 if (ks == 0 && more) {                                       // one LDS-DMA instruction of stage kt+1 behind every 4 MFMAs
-                    if (ii < 4) v3_stage_one(A, p.lda, m0, p.M, (kt + 1) * BK, nbuf, w * 4 + ii, lane);
-                    else v3_stage_one(B, p.ldb, n0, p.N, (kt + 1) * BK, nbuf + V3_BM * BK * 2, w * 4 + ii - 4, lane);
+                    if (ii < 4) stage_one(A, p.lda, m0, p.M, (kt + 1) * BK, nbuf, w * 4 + ii, lane);
+                    else stage_one(B, p.ldb, n0, p.N, (kt + 1) * BK, nbuf + V3_BM * BK * 2, w * 4 + ii - 4, lane);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
