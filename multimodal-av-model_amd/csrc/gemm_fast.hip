@@ -631,18 +631,21 @@ __global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v3 (EXPERIMENTAL, off by default; AVAMD_GEMM_V3=1 for N >= 2048, =2 for every NT product): 256 x 256 x 64 tile, 8 wavefronts
+// v3 (EXPERIMENTAL, off by default; AVAMD_GEMM_V3 = 1: N >= 4096 with K < 2048, 2: every NT product): 256 x 256 x 64 tile, 8 wavefronts
 // as 2 (M) x 4 (N) with 128 x 64 each (128 accumulator registers), two LDS stages of 64 KiB.
-// Measured (8192^3, random operands): this form 1.18 PF/s; the same tile with BK = 32, 64-B rows and a FOUR-stage ring (three K-steps
-// in flight) 1.09-1.10 PF/s whatever the barrier structure (plain, stage hand-over in the middle of the MFMA block with the next
-// fragments read under its second half, two wavefront groups staggered by half a K-step, s_setprio around the MFMAs: all within
-// 1 %); the 128 x 128 kernel 1.15-1.22, the vendor library's 256 x 256 stream-K kernel 1.55.  Reading: a 64-B row costs a full line
-// request on the LDS-DMA path (lines per MAC: 128 x 128 x 64 -> 1, 256 x 128 x 64 -> 0.75, 256 x 256 x 64 -> 0.5, 256 x 256 x 32 -> 1),
-// so rows stay 128 B; with 64 KiB per stage only ONE K-step can be in flight in 160 KiB of LDS, and a K-step then costs about its
-// 2048 MFMA clocks PLUS the tail of its DMA (64 KiB at ~32 B/clk is also ~2048 clocks, issued after the barrier): ~52 % MFMA
-// utilisation, as measured.  The missing piece is half-tile granularity (8 x 16 KiB slots, three half-tiles always in flight, one
-// C quadrant per phase: guide section 5), not the tile shape.  On 6368 x 4096 x 1024 (400 tiles on 256 CUs) it equals the 128 x 128
-// kernel (74 us), so it is not dispatched by default; with stream-K it is the candidate for the wide K = 1024 products.
+// Measured (8192^3, random operands; core-clock stamps: tools/v3_stamps.cpp):
+//   * two plain stages, the 8 LDS-DMA instructions of a wavefront issued in one burst after the barrier: 1.18 PF/s.  Stamps: the
+//     data wait is ~30 clocks (the DMA has long landed) but the ISSUE of the burst holds a wavefront 600-1300 clocks (64 instructions x
+//     8 lines queue at the CU's address unit) with the MFMA pipes idle: 3290 clocks per K-tile against 2048 of MFMA work;
+//   * the same instructions spread over the MFMA groups: 2650 clocks per K-tile, 1.25 PF/s - 77 % MFMA utilisation; the clock under
+//     this load is ~1.55 GHz (2650 clocks in 1.72 us), so the attainable peak is ~1.6 PF/s, not 2.5;
+//   * + rolling fragment window with the stage hand-over inside the MFMA block (this form): 1.22 PF/s at 8192^3, 67 us on
+//     6368 x 4096 x 1024 (128 x 128 kernel: 72, previous form: 69); wavefronts 0-3 still wait ~700 clocks at the barrier for 4-7
+//     (issue priority on the shared SIMD);
+//   * BK = 32 with 64-B rows and a four-stage ring: 1.09-1.10 PF/s whatever the barrier structure (mid-step hand-over, staggered
+//     wavefront groups, s_setprio): a 64-B row costs a full line request; a ring of ten 16-KiB half-tiles with burst issue: 1.05;
+//   * 128 x 128 kernel 1.15-1.22, 256 x 128 three-stage 1.2 (spreading its DMA issue changed nothing: two of its three stages are
+//     already in flight), vendor library 256 x 256 stream-K 1.55.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int V3_BM = 256, V3_BN = 256, V3_NT = 512;
 constexpr int V3_STAGE = (V3_BM + V3_BN) * BK * 2;          // 65 536 B
@@ -694,49 +697,78 @@ __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm
 #else
 #define V3_STAMP(x)
 #endif
+    // A K-tile is 16 MFMA groups G = 8 ks + ii (4 MFMAs each: one m-tile x four n-tiles).  Fragments roll through registers: the A
+    // fragment of group G+2 is read at group G (ring of 4), the B fragments of the second K-half at G = 5, and - across the tile
+    // boundary - the next tile's B fragments and first two A fragments at G = 13 .. 15.  The stage hand-over (vmcnt + barrier) sits
+    // in front of G = 13, AFTER every read of this stage (groups 13 .. 15 already hold their fragments), so the barrier skew and the
+    // LDS latency of the first fragments of the next tile are covered by the 12 MFMAs still queued.  The 8 LDS-DMA instructions of
+    // stage kt+1 go out two per group at G = 0 .. 3 (not as one burst: see the stamps above).
+    bf16x8 bA[4], bB[4], ar[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // stage 0 landed for everyone
+    asm volatile("" ::: "memory");
+    {
+        const int ch0 = (g ^ sw) << 4;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bA[jj] = *(const bf16x8*)(smem + b_off + jj * 2048 + ch0);
+        ar[0] = *(const bf16x8*)(smem + a_off + ch0);
+        ar[1] = *(const bf16x8*)(smem + a_off + 2048 + ch0);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         V3_STAMP(ts0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // my LDS-DMA of stage kt landed ...
-        V3_STAMP(ts1)
-        __builtin_amdgcn_s_barrier();                                       // ... everyone's; every wavefront is done reading stage kt-1
-        asm volatile("" ::: "memory");
-        V3_STAMP(ts2)
-        // the 8 LDS-DMA instructions of stage kt+1 are NOT issued here in one burst: measured with core-clock stamps
-        // (tools/v3_stamps.cpp), a burst right after the barrier holds every wavefront for 600-1300 clocks (64 instructions x 8
-        // lines queue at the CU's address unit) while the MFMA pipes idle; they go out one per m-tile group of the first K-half below
         const bool more = kt + 1 < nk;
         char* nbuf = smem + ((kt + 1) & 1) * V3_STAGE;
-        V3_STAMP(ts3)
         const char* sa = smem + (kt & 1) * V3_STAGE + a_off;
         const char* sb = smem + (kt & 1) * V3_STAGE + b_off;
+        const int chk[2] = {(g ^ sw) << 4, ((4 + g) ^ sw) << 4};
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ((ks * 4 + g) ^ sw) << 4;
-            bf16x8 b[4], a[3];                                               // A fragments two m-tiles ahead of their MFMAs
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) b[jj] = *(const bf16x8*)(sb + jj * 2048 + ch);
-            a[0] = *(const bf16x8*)(sa + ch);
-            a[1] = *(const bf16x8*)(sa + 2048 + ch);
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii) {
-                if (ii + 2 < 8) a[(ii + 2) % 3] = *(const bf16x8*)(sa + (ii + 2) * 2048 + ch);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ii % 3], b[jj], acc[ii][jj], 0, 0, 0);
-                if (ks == 0 && more) {                                       // one LDS-DMA instruction of stage kt+1 behind every 4 MFMAs
-                    if (ii < 4) stage_one(A, p.lda, m0, p.M, (kt + 1) * BK, nbuf, w * 4 + ii, lane);
-                    else stage_one(B, p.ldb, n0, p.N, (kt + 1) * BK, nbuf + V3_BM * BK * 2, w * 4 + ii - 4, lane);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+        for (int G = 0; G < 16; ++G) {
+            const int ks = G >> 3, ii = G & 7;
+            // ---- fragment reads issued at this group
+            if (G <= 11) { const int H = G + 2; ar[H & 3] = *(const bf16x8*)(sa + (H & 7) * 2048 + chk[H >> 3]); }
+            if (G == 12) {
+                ar[14 & 3] = *(const bf16x8*)(sa + 6 * 2048 + chk[1]);
+                ar[15 & 3] = *(const bf16x8*)(sa + 7 * 2048 + chk[1]);
             }
+            if (G == 5) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bB[jj] = *(const bf16x8*)(sb + jj * 2048 + chk[1]);
+            }
+            if (G == 13 && more) {                                           // hand-over: every read of stage kt has been issued (and is waited for here)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                V3_STAMP(tw0)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my LDS-DMA of stage kt+1 landed ...
+                V3_STAMP(tw1)
+                __builtin_amdgcn_s_barrier();                               // ... everyone's; stage kt is free for the DMA of tile kt+2
+                asm volatile("" ::: "memory");
+                V3_STAMP(tw2)
+#ifdef AV_V3_STAMPS
+                st_wait += tw1 - tw0; st_bar += tw2 - tw1;
+#endif
+                const char* nb_ = smem + ((kt + 1) & 1) * V3_STAGE;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bA[jj] = *(const bf16x8*)(nb_ + b_off + jj * 2048 + chk[0]);
+            }
+            if (G == 14 && more) ar[16 & 3] = *(const bf16x8*)(smem + ((kt + 1) & 1) * V3_STAGE + a_off + chk[0]);
+            if (G == 15 && more) ar[17 & 3] = *(const bf16x8*)(smem + ((kt + 1) & 1) * V3_STAGE + a_off + 2048 + chk[0]);
+            // ---- 4 MFMAs of group G.  bA is overwritten at G = 13 with the NEXT tile's fragments, so the second K-half uses bB only
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[G & 3], ks ? bB[jj] : bA[jj], acc[ii][jj], 0, 0, 0);
+            if (G < 4 && more) {                                             // two LDS-DMA instructions of stage kt+1 behind these MFMAs
+                stage_one(A, p.lda, m0, p.M, (kt + 1) * BK, nbuf, w * 4 + G, lane);
+                stage_one(B, p.ldb, n0, p.N, (kt + 1) * BK, nbuf + V3_BM * BK * 2, w * 4 + G, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): my reads of stage kt are complete before the next barrier
 #ifdef AV_V3_STAMPS
         V3_STAMP(ts4)
-        st_wait += ts1 - ts0; st_bar += ts2 - ts1; st_issue += ts3 - ts2; st_mma += ts4 - ts3;
+        st_mma += ts4 - ts0;
 #endif
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
 #ifdef AV_V3_STAMPS
-    if (lane == 0 && (w == 0 || w == 5) && p.aux) {                         // [2 wavefronts][5]: wait, barrier, DMA issue, reads + MFMA issue, K-tiles
+    if (lane == 0 && (w == 0 || w == 5) && p.aux) {                         // [2 wavefronts][5]: wait, barrier, -, whole K-tile, K-tiles
         unsigned long long* d = (unsigned long long*)p.aux + (w == 0 ? 0 : 5);
         atomicAdd(d + 0, st_wait); atomicAdd(d + 1, st_bar); atomicAdd(d + 2, st_issue); atomicAdd(d + 3, st_mma); atomicAdd(d + 4, (unsigned long long)nk);
     }
@@ -835,8 +867,11 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         if (akm) return launch_fast<128, false, true, false>(p, st, fl);
         return launch_fast<128, false, false, true>(p, st, fl);
     }
-    static const int v3_mode = [] { const char* e = getenv("AVAMD_GEMM_V3"); return e ? atoi(e) : 0; }();   // experimental 256 x 256 kernel: 0 never, 1 when N >= 2048, 2 for every NT product
-    if (!conv && !narrow && v3_mode > 0 && p.M >= 512 && p.N >= (v3_mode == 1 ? 2048 : 256)) {
+    // 256 x 256 kernel: 0 (default) never, 1 for the wide short-K products (N >= 4096, K < 2048: the FFN-up forward and the FFN-down dX;
+    // 67 us against 72 us for the 128 x 128 kernel in isolation, but 0.1 ms SLOWER per training step - GELU / second-output epilogue in
+    // two halves, one workgroup per CU beside the side stream's kernels), 2 for every NT product (tests / diagnostics)
+    static const int v3_mode = [] { const char* e = getenv("AVAMD_GEMM_V3"); return e ? atoi(e) : 0; }();
+    if (!conv && !narrow && v3_mode > 0 && p.M >= 2048 && (v3_mode >= 2 ? p.N >= 256 : (p.N >= 4096 && p.K < 2048))) {
         static bool v3_attr = false;
         if (!v3_attr) {
             if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS) != hipSuccess) {
