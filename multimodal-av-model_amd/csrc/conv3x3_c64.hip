@@ -81,22 +81,23 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { xs[e] = p.in_scale[cg + e]; xb[e] = p.in_shift[cg + e]; xl[e] = p.in_slope ? p.in_slope[cg + e] : 1.f; }
     }
-    auto stage = [&](int t) {
+    // k-th of this wavefront's 10 LDS-DMA instructions of window t.  Window 0 goes out as one burst; window t+1 is issued ONE
+    // instruction per MFMA step inside tile t's loop: a burst holds the issuing wavefront for hundreds of clocks at the CU's address
+    // unit (measured on the GEMM: tools/v3_stamps.cpp), and issued behind tile t's output stores it also made the next tile's
+    // vmcnt wait cover those stores.
+    auto stage_k = [&](int t, int k) {
         const int tile = (int)blockIdx.x + t * G;
         const long long q0 = (long long)tile * CM - (p.W + 1);
         char* buf = Win + (t & 1) * WIN_BYTES;
-#pragma unroll
-        for (int k = 0; k < NINSTR / 4; ++k) {
-            const int ins = k * 4 + w;
-            long long q = q0 + ins * 8 + sub;
-            q = q < 0 ? 0 : (q > p.M - 1 ? p.M - 1 : q);                                // out-of-range rows are never used unmasked
-            const bf16_t* src = p.x + q * 64 + choff;
-            const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(ins * 1024));
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + off), 16, 0, 0);
-        }
+        const int ins = k * 4 + w;
+        long long q = q0 + ins * 8 + sub;
+        q = q < 0 ? 0 : (q > p.M - 1 ? p.M - 1 : q);                                    // out-of-range rows are never used unmasked
+        const bf16_t* src = p.x + q * 64 + choff;
+        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(ins * 1024));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + off), 16, 0, 0);
     };
-    stage(0);
-    if (T > 1) stage(1);
+#pragma unroll
+    for (int k = 0; k < NINSTR / 4; ++k) stage_k(0, k);
 
     const float invW = 1.0f / (float)p.W, invH = 1.0f / (float)p.H;
     for (int t = 0; t < T; ++t) {
@@ -119,10 +120,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
             if (px < p.M) m = (yy > 0 ? 1u : 0u) | 2u | (yy < p.H - 1 ? 4u : 0u) | (xx > 0 ? 8u : 0u) | 16u | (xx < p.W - 1 ? 32u : 0u);
             vm[i] = m;
         }
-        // my 10 LDS-DMA instructions of window t have landed (those of window t+1 may still fly), then everyone's
-        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        // my 10 LDS-DMA instructions of window t have landed - they were issued during tile t-1's MFMA loop; the output /
+        // statistics stores of tile t-1 behind them may still be in flight - then everyone's
+        if (t > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // 8 output stores per wavefront are newer than the window (+ 1 statistics store in wavefronts 0, 1)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wg_barrier();
+        const bool more = t + 1 < T;
         char* win = Win + (t & 1) * WIN_BYTES;
         if constexpr (XF) {                                                           // 320 rows x 8 chunks = 10 chunks per thread, in place
             uint4 tv[NINSTR / 4];
@@ -171,11 +174,13 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
             C64_LOAD(wfB, pfB, st + 1)
             __builtin_amdgcn_sched_barrier(0);
             C64_MMA(wfA, pfA, st)
+            if (more) stage_k(t + 1, st / 2);                                            // windows t+1: instructions 0 .. 8 here, 9 below
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);                                          // set B is complete
             if (st + 2 < 18) C64_LOAD(wfA, pfA, st + 2)
             __builtin_amdgcn_sched_barrier(0);
             C64_MMA(wfB, pfB, st + 1)
+            if (more && st == 0) stage_k(t + 1, 9);
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef C64_LOAD
@@ -234,8 +239,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
             p.stats[((long long)tile * 2 + which) * 64 + c] =
                 St[(0 * 2 + which) * 64 + c] + St[(1 * 2 + which) * 64 + c] + St[(2 * 2 + which) * 64 + c] + St[(3 * 2 + which) * 64 + c];
         }
-        wg_barrier();                                                                // staging buffer drained: refill it
-        if (t + 2 < T) stage(t + 2);
+        wg_barrier();                                                                // staging buffer drained: tile t+1's loop refills it
     }
 }
 
