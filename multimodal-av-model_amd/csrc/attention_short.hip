@@ -127,11 +127,14 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short_kernel(const AttnP p) {
             }
         if (DROP) {
             const float ik = 1.0f / (1.0f - p.drop_p);
-            const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * p.Tk;
+            const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * ((p.Tk + 3) & ~3);      // multiple of 4
 #pragma unroll
-            for (int t = 0; t < 2 * NKP; ++t)
+            for (int t = 0; t < 2 * NKP; ++t) {                // my 4 keys of tile t are consecutive and 4-aligned: ONE Philox call
+                float m4[4];
+                drop_mult4(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g), p.drop_p, ik, m4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) S[t][e] *= drop_mult_call(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g + e), p.drop_p, ik);
+                for (int e = 0; e < 4; ++e) S[t][e] *= m4[e];
+            }
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
@@ -225,11 +228,14 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_long_kernel(const AttnP p) {
             }
         if (DROP) {
             const float ik = 1.0f / (1.0f - p.drop_p);
-            const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * p.Tk + k0;
+            const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * ((p.Tk + 3) & ~3) + k0;
 #pragma unroll
-            for (int t = 0; t < 2 * NKP; ++t)
+            for (int t = 0; t < 2 * NKP; ++t) {
+                float m4[4];
+                drop_mult4(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g), p.drop_p, ik, m4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) S[t][e] *= drop_mult_call(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g + e), p.drop_p, ik);
+                for (int e = 0; e < 4; ++e) S[t][e] *= m4[e];
+            }
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
                     const int q = q0 + 4 * g + e;
                     const float pv = (kok && q < p.Tq) ? __builtin_amdgcn_exp2f(s[e] * c - l4[e]) : 0.f;
                     float dm = 1.f;
-                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + q) * p.Tk + krow, p.drop_p, ik);
+                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + q) * ((p.Tk + 3) & ~3) + krow, p.drop_p, ik);
                     Pt[hf][e] = pv * dm;
                     St[hf][e] = pv * (dp[e] * dm - d4[e]) * p.scale;
                 }
@@ -394,13 +400,13 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
                 s = mfma(row_frag(I0, k0 + r, 4 + g), qf1, s);
                 dp = mfma(row_frag(I1, k0 + r, g), of0, dp);
                 dp = mfma(row_frag(I1, k0 + r, 4 + g), of1, dp);
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) drop_mult4(p.drop_seed, p.drop_stream, (dbase + qrow) * ((p.Tk + 3) & ~3) + (k0 + 4 * g), p.drop_p, ik, m4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int key = k0 + 4 * g + e;
                     const float pv = (qok && key < klen) ? __builtin_amdgcn_exp2f(s[e] * c - lq) : 0.f;
-                    float dm = 1.f;
-                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + qrow) * p.Tk + key, p.drop_p, ik);
-                    St[hf][e] = pv * (dp[e] * dm - dq_) * p.scale;
+                    St[hf][e] = pv * (dp[e] * m4[e] - dq_) * p.scale;
                 }
             }
             const bf16x8 sf = pack8(St[0], St[1]);
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_long_kv_kernel(const BwdP p) {
                     const int q = q0 + ql + 4 * g + e;
                     const float pv = (kok && q < p.Tq) ? __builtin_amdgcn_exp2f(sv[e] * c - l4[e]) : 0.f;
                     float dm = 1.f;
-                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + q) * p.Tk + krow, p.drop_p, ik);
+                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + q) * ((p.Tk + 3) & ~3) + krow, p.drop_p, ik);
                     Pt[hf][e] = pv * dm;
                     St[hf][e] = pv * (dp[e] * dm - d4[e]) * p.scale;
                 }
@@ -588,13 +594,13 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_long_q_kernel(const BwdP p) {
                 sv = mfma(row_frag(I0, kl + r, 4 + g), qf1, sv);
                 dp = mfma(row_frag(I1, kl + r, g), of0, dp);
                 dp = mfma(row_frag(I1, kl + r, 4 + g), of1, dp);
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) drop_mult4(p.drop_seed, p.drop_stream, (dbase + qrow) * ((p.Tk + 3) & ~3) + (k0 + kl + 4 * g), p.drop_p, ik, m4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int key = k0 + kl + 4 * g + e;
                     const float pv = (qok && key < klen) ? __builtin_amdgcn_exp2f(sv[e] * c - lq) : 0.f;
-                    float dm = 1.f;
-                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + qrow) * p.Tk + key, p.drop_p, ik);
-                    St[hf][e] = pv * (dp[e] * dm - dq_) * p.scale;
+                    St[hf][e] = pv * (dp[e] * m4[e] - dq_) * p.scale;
                 }
             }
             const bf16x8 sf = pack8(St[0], St[1]);

@@ -17,6 +17,8 @@ struct AttnP {
     unsigned long long drop_seed;
 };
 
+// Attention-probability dropout: element (b, h, q, k) uses Philox element index ((b H + h) Tq + q) * Tk4 + k with the row pitch
+// Tk4 = Tk rounded up to 4, so four consecutive keys of one query always share ONE Philox block (drop_mult4) in every kernel.
 struct BwdP {
     const bf16_t *q, *k, *v, *o, *dout;
     const float *lse, *delta;
