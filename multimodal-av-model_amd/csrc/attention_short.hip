@@ -266,6 +266,27 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_long_kernel(const AttnP p) {
     }
 }
 
+// Dropout multipliers of the kv-owner phases: a lane holds P[q = qb + e][key = krow], e = 0..3 - four different Philox rows.  The four
+// lanes of a quad (keys krow & ~3 .. + 3, same four queries) share the four blocks: lane j of the quad evaluates the block of query
+// qb + j (its four keys) and the values travel by quad-permute DPP moves, so a lane pays ONE Philox call for its four elements.
+template <int SRC>
+__device__ __forceinline__ float quad_from(float v) {          // value of lane SRC of my quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), SRC * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void drop_quad4(unsigned long long seed, unsigned stream, unsigned long long row0_idx, unsigned long long pitch,
+                                           int krow, int r, float p, float ik, float (&dm)[4]) {
+    float m4[4];                                                // my block: query qb + (r & 3), keys (krow & ~3) + 0..3
+    drop_mult4(seed, stream, row0_idx + (unsigned long long)(r & 3) * pitch + (unsigned long long)(krow & ~3), p, ik, m4);
+    const int pos = r & 3;                                      // my key's position inside every block
+    float got[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        got[0][j] = quad_from<0>(m4[j]); got[1][j] = quad_from<1>(m4[j]); got[2][j] = quad_from<2>(m4[j]); got[3][j] = quad_from<3>(m4[j]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dm[e] = pos == 0 ? got[e][0] : (pos == 1 ? got[e][1] : (pos == 2 ? got[e][2] : got[e][3]));
+}
+
 // ---------------------------------------------------------------------------------------------------- backward
 template <bool DROP>
 __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int R) {
@@ -341,14 +362,14 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
                 dp = mfma(row_frag(I1, q0 + r, g), vf0, dp);
                 dp = mfma(row_frag(I1, q0 + r, 4 + g), vf1, dp);
                 const f32x4 l4 = *(const f32x4*)(lse_s + q0 + 4 * g), d4 = *(const f32x4*)(del_s + q0 + 4 * g);
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) drop_quad4(p.drop_seed, p.drop_stream, (dbase + q0 + 4 * g) * ((p.Tk + 3) & ~3), (unsigned long long)((p.Tk + 3) & ~3), krow, r, p.drop_p, ik, dm);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int q = q0 + 4 * g + e;
                     const float pv = (kok && q < p.Tq) ? __builtin_amdgcn_exp2f(s[e] * c - l4[e]) : 0.f;
-                    float dm = 1.f;
-                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + q) * ((p.Tk + 3) & ~3) + krow, p.drop_p, ik);
-                    Pt[hf][e] = pv * dm;
-                    St[hf][e] = pv * (dp[e] * dm - d4[e]) * p.scale;
+                    Pt[hf][e] = pv * dm[e];
+                    St[hf][e] = pv * (dp[e] * dm[e] - d4[e]) * p.scale;
                 }
             }
             const bf16x8 pf = pack8(Pt[0], Pt[1]), sf = pack8(St[0], St[1]);
@@ -506,14 +527,14 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_long_kv_kernel(const BwdP p) {
                 dp = mfma(row_frag(I1, ql + r, g), vf0, dp);
                 dp = mfma(row_frag(I1, ql + r, 4 + g), vf1, dp);
                 const f32x4 l4 = *(const f32x4*)(lse_s + ql + 4 * g), d4 = *(const f32x4*)(del_s + ql + 4 * g);
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) drop_quad4(p.drop_seed, p.drop_stream, (dbase + q0 + ql + 4 * g) * ((p.Tk + 3) & ~3), (unsigned long long)((p.Tk + 3) & ~3), krow, r, p.drop_p, ik, dm);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int q = q0 + ql + 4 * g + e;
                     const float pv = (kok && q < p.Tq) ? __builtin_amdgcn_exp2f(sv[e] * c - l4[e]) : 0.f;
-                    float dm = 1.f;
-                    if (DROP) dm = drop_mult_call(p.drop_seed, p.drop_stream, (dbase + q) * ((p.Tk + 3) & ~3) + krow, p.drop_p, ik);
-                    Pt[hf][e] = pv * dm;
-                    St[hf][e] = pv * (dp[e] * dm - d4[e]) * p.scale;
+                    Pt[hf][e] = pv * dm[e];
+                    St[hf][e] = pv * (dp[e] * dm[e] - d4[e]) * p.scale;
                 }
             }
             const bf16x8 pf = pack8(Pt[0], Pt[1]), sf = pack8(St[0], St[1]);
