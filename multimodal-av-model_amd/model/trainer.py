@@ -187,16 +187,21 @@ class MultimodalTrainer:
             vf1 = self.visual_encoder(d["lip1"])
             vf2 = self.visual_encoder(d["lip2"])
         attn1 = d["mask1"] != 3
-        a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1)
         passes = self.audio_passes
         if passes is None:      # auto: the duplicate pass only differs when a stochastic regulariser is active in train mode
             cfg = getattr(self.audio_encoder.model, "cfg", {})
             knobs = ("hidden_dropout", "attention_dropout", "activation_dropout", "feat_proj_dropout", "layerdrop", "mask_time_prob")
             passes = 2 if (self.audio_encoder.training and any(cfg.get(k, 0) > 0 for k in knobs)) else 1
         if passes == 2:
-            a2, mid2 = self.audio_encoder(d["audio"], attention_mask=(d["mask2"] != 3))
-        else:
-            a2, mid2 = a1, mid1
+            self.audio_encoder.model._feat_cache = {}              # both passes read the same waveform: one conv feature-extractor run
+        try:
+            a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1)
+            if passes == 2:
+                a2, mid2 = self.audio_encoder(d["audio"], attention_mask=(d["mask2"] != 3))
+            else:
+                a2, mid2 = a1, mid1
+        finally:
+            self.audio_encoder.model._feat_cache = None
         T_enc, D = a1.shape[1], a1.shape[2]
         m1 = self._mask_ds(d["mask1"], T_enc)
         m2 = self._mask_ds(d["mask2"], T_enc)

@@ -230,8 +230,17 @@ class Wav2Vec2ModelHIP(nn.Module):
         fp_p = sc["feat_proj_dropout"] if tm else 0.0
         ld_p = sc["layerdrop"] if tm else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (hd_p or at_p or ac_p or fp_p) else 0
-        wav = wav.contiguous().float()
-        feats = self.features(wav, dtype)
+        # the conv feature extractor is frozen and has no stochastic op, so two passes over the SAME waveform tensor (the reference's
+        # audio_encoder(audio, mask1) / (audio, mask2), model/trainer.py:88-96) share its output while the trainer holds the window open
+        fc = getattr(self, "_feat_cache", None)
+        if fc is not None and fc.get("src") is wav and fc.get("dtype") == dtype:
+            feats = fc["feats"]
+        else:
+            src = wav
+            wav = wav.contiguous().float()
+            feats = self.features(wav, dtype)
+            if fc is not None:
+                fc["src"], fc["dtype"], fc["feats"] = src, dtype, feats
         B, T, C = feats.shape
         klen = keep = None
         if attention_mask is not None:

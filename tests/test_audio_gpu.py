@@ -76,3 +76,29 @@ def test_audio_c1_golden(precision, tol):
         last, mid = ae(batch["audio"].cuda(), attention_mask=(batch["mask1"] != 3).cuda())
     assert float(np.abs(last.cpu().numpy()[..., ::8] - fx["eval_audio_last"]).max()) < tol
     assert float(np.abs(mid.cpu().numpy()[..., ::8] - fx["eval_audio_mid"]).max()) < tol
+
+
+def test_two_passes_share_the_conv_feature_extractor():
+    """The trainer opens a window (model._feat_cache) around the reference's two audio passes over the SAME waveform: the frozen,
+    deterministic conv feature extractor runs once, results are unchanged; outside the window nothing is cached."""
+    init = pkg("utils.init"); enc = pkg("model.encoder"); synth = pkg("dataset.synthetic")
+    pkg("precision").set_precision("bf16")
+    cfg = init.W2V2_TINY
+    ae = enc.AudioEncoder(dict(cfg), freeze=True).cuda(); ae.load_state_dict(init.w2v2_state_dict(cfg)); ae.eval()
+    batch = synth.make_batch(3, 1.0, seed=8, ragged=True)
+    wav, m1, m2 = batch["audio"].cuda(), (batch["mask1"] != 3).cuda(), (batch["mask2"] != 3).cuda()
+    calls = []
+    orig = ae.model.features
+    ae.model.features = lambda w, dt: (calls.append(1), orig(w, dt))[1]
+    with torch.no_grad():
+        ref1, _ = ae(wav, m1); ref2, _ = ae(wav, m2)
+        assert len(calls) == 2
+        ae.model._feat_cache = {}
+        try:
+            a1, _ = ae(wav, m1); a2, _ = ae(wav, m2)
+        finally:
+            ae.model._feat_cache = None
+        assert len(calls) == 3                                     # one extractor run for the two passes inside the window
+        a3, _ = ae(wav, m1)
+        assert len(calls) == 4
+    assert torch.equal(a1, ref1) and torch.equal(a2, ref2) and torch.equal(a3, ref1)
