@@ -46,7 +46,9 @@ def flops_per_utt(cfg, T_audio, T_v, audio_passes):
     Ab = 14 * (lin + 2 * att) + 4 * (2 * lin + 2 * att)
     V = 695.2e6 * T_v
     F = T_v * (2 * 512 ** 2 + 2 * 1024 * 512 + 8 * 512 ** 2 + 2 * 512 ** 2 + 2 * 4 * 512 * (1024 + 1536) * 2 + 2 * 1024 * 800) + 4.0 * T_v ** 2 * 512
-    return audio_passes * (A + Ab) + 2 * V + 2 * F + 2 * 2 * F
+    # with two audio passes the frozen, dropout-free conv feature extractor runs ONCE (model/trainer.py: shared between the passes):
+    # count what is executed
+    return audio_passes * (A + Ab) - (audio_passes - 1) * conv + 2 * V + 2 * F + 2 * 2 * F
 
 
 def cpu_baseline(cfg, seconds):
