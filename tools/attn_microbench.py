@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("multimodal-av-model_amd.ops")
 
-for (B, H, T, D) in [(32, 16, 199, 64), (64, 16, 199, 64), (2, 16, 49, 64), (8, 16, 256, 64)]:
+for (B, H, T, D) in [(32, 16, 199, 64), (64, 16, 199, 64), (2, 16, 49, 64), (8, 16, 256, 64), (8, 16, 749, 64)]:
     qkv = torch.randn(B, T, 3, H, D, device="cuda").to(torch.bfloat16)
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
     klen = torch.full((B,), T, device="cuda", dtype=torch.int32)
