@@ -1,10 +1,14 @@
 """Benchmark of the hot path: utterances/sec of the full audio-visual CTC training step (fwd + bwd + Adam).
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W            (N > 1: one rank per GPU over RCCL)
 
-Workload at N=1 = BASELINE.json configs[1]: batch 32 x 4 s clips (64 000 samples @16 kHz + 100 lip frames 96x96 per
-speaker), wav2vec2-large architecture, random-init weights, synthetic data, bf16 MFMA compute with fp32 master
-weights; N > 1 keeps the per-GPU batch (weak scaling) and all-reduces the 63.8 M trainable gradients over RCCL.
+Workload = the configuration BASELINE.json's metric is quoted on: batch 64 per GPU x 4 s clips (64 000 samples @16 kHz + 100 lip
+frames 96x96 per speaker), wav2vec2-large architecture, random-init weights, synthetic data, bf16 MFMA compute with fp32 master
+weights; N > 1 keeps the per-GPU batch (weak scaling) and all-reduces the 63.8 M trainable gradients over RCCL
+(``python bench.py --gpus N`` starts its own N ranks; under torch.distributed.run it is one of them).
+Headline ``value`` = the step AS THE REFERENCE EXECUTES IT: two wav2vec2 passes per step (model/trainer.py:94-95) with the HF-default
+train-mode regularisers (dropout 0.1, LayerDrop 0.1, SpecAugment 0.05).  ``other_variant`` = the deterministic parity configuration
+(all regularisers 0), where the two passes are bit-identical and the encoder runs once.
 Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
 """
 from __future__ import annotations
@@ -72,16 +76,59 @@ def cpu_baseline(cfg, seconds):
             "sample": f"B={B} x {seconds:g} s clips, {n} fp32 steps after 1 warm-up, two audio passes as the reference runs it"}
 
 
+HF_REGULARIZERS = dict(hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, feat_proj_dropout=0.0, layerdrop=0.1,
+                       mask_time_prob=0.05, mask_time_length=10, mask_time_min_masks=2)
+NO_REGULARIZERS = dict(hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0,
+                       mask_time_prob=0.0)
+
+
+def spawn_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` as typed: this process has not touched the GPU yet, so it starts N fresh ranks under
+    torch.distributed.run (one per GPU, RCCL), relays their output and returns their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def attention_report(records, steps):
+    """SURVEY §8(d) attention-kernel report: per kernel (K7 = wav2vec2 self-attention, head_dim 64; K17 = fusion cross-attention,
+    head_dim 128), forward and backward: average launch time (events on the launch stream), algorithmic TFLOP/s against the dense
+    bf16 MFMA peak and algorithmic GB/s against the HBM peak."""
+    out = {}
+    names = {"fwd64": "K7_w2v2_self_attention_fwd", "bwd64": "K7_w2v2_self_attention_bwd",
+             "fwd128": "K17_fusion_cross_attention_fwd", "bwd128": "K17_fusion_cross_attention_bwd",
+             "blockfwd": "K17_fused_block_fwd", "blockbwd": "K17_fused_block_bwd"}
+    for tag in sorted({r[2] for r in records}):
+        rs = [r for r in records if r[2] == tag]
+        ms = sum(r[0].elapsed_time(r[1]) for r in rs)
+        fl = sum(r[3] for r in rs); by = sum(r[4] for r in rs)
+        tf = fl / (ms * 1e-3) / 1e12
+        gb = by / (ms * 1e-3) / 1e9
+        out[names.get(tag, tag)] = {"avg_launch_us": round(1e3 * ms / len(rs), 2), "launches_per_step": len(rs) // max(1, steps),
+                                    "algorithmic_gflop_per_launch": round(fl / len(rs) / 1e9, 3), "tflops": round(tf, 1),
+                                    "frac_of_mfma_peak": round(tf / 2500.0, 4), "algorithmic_mb_per_launch": round(by / len(rs) / 1e6, 2),
+                                    "gb_per_s": round(gb, 1), "frac_of_hbm_peak": round(gb / 8000.0, 4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[1]: 32)")
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json metric: batch 64)")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--audio-passes", type=int, default=None, choices=[1, 2], help="default: 1 (deterministic mode), 2 with --regularize")
-    ap.add_argument("--regularize", action="store_true", help="HF-default dropout 0.1 / LayerDrop 0.1 / SpecAugment 0.05 and two audio passes")
+    ap.add_argument("--variant", default="as_executed", choices=["as_executed", "deterministic"],
+                    help="headline variant.  as_executed: two audio passes with HF-default dropout / LayerDrop / SpecAugment, what the reference's "
+                         "train_epoch runs (model/trainer.py:94-95); deterministic: every regulariser 0 (the parity configuration), where the "
+                         "two passes are bit-identical and the encoder runs once")
+    ap.add_argument("--single-variant", action="store_true", help="time only the headline variant")
     ap.add_argument("--lambda", dest="lambda_", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
@@ -91,12 +138,13 @@ def main():
     ap.add_argument("--no-pair", action="store_true", help="one fusion/decoder call per speaker, as the reference does")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))        # nothing above has initialised the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if args.same_device:
         local = 0
         # rehearsal only: the ranks share ONE GPU, where the persistent BiLSTM kernels of two processes cannot all be resident at once
@@ -116,11 +164,6 @@ def main():
     L = imp("_lib")
     imp("precision").set_precision(args.precision)
     cfg = dict(init.W2V2_LARGE)
-    if args.regularize:
-        cfg.update(hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, feat_proj_dropout=0.0, layerdrop=0.1,
-                   mask_time_prob=0.05, mask_time_length=10, mask_time_min_masks=2)
-    if args.audio_passes is None:
-        args.audio_passes = 2 if args.regularize else 1
 
     ve = enc.VisualEncoder(); ve.load_state_dict(init.visual_state_dict())
     for p in ve.parameters():
@@ -132,7 +175,7 @@ def main():
     de = dm.CTCDecoder(1024, 800, 3); de.load_state_dict(init.decoder_state_dict(1024, 800))
     reducer = dp.GradBucketReducer() if world > 1 else None
     t = tr.MultimodalTrainer(ve, ae, fu, de, tok.SyntheticTokenizer(800), learning_rate=1e-4, device=dev, lambda_=args.lambda_,
-                             audio_passes=args.audio_passes, reducer=reducer, pair_batched=not args.no_pair,
+                             audio_passes=None, reducer=reducer, pair_batched=not args.no_pair,
                              visual_side_stream=not args.no_side_stream)
     t.fixed_projection = init.projection_params(cfg["hidden_size"])      # identical on every rank (SURVEY §8e caveat 4)
     t.visual_encoder.train(); t.audio_encoder.train(); t.fusion_module.train(); t.decoder1.train()
@@ -149,77 +192,111 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    for _ in range(args.warmup):
-        out = t.train_step(batch)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = t.train_step(batch)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # roofline leg: the SAME workload for a few more steps with per-launch events around the dominant kernel.  The
-    # side stream is switched off here so that the events bracket only the kernel (with two streams the elapsed time
+    def set_variant(v):
+        """The trainer picks the number of audio passes itself (two as soon as a regulariser is active in train mode)."""
+        ae.model.cfg.update(HF_REGULARIZERS if v == "as_executed" else NO_REGULARIZERS)
+        return 2 if v == "as_executed" else 1
+
+    def timed(v):
+        passes = set_variant(v)
+        torch.manual_seed(1234 + rank)
+        import numpy as np
+        np.random.seed(1234 + rank)
+        for _ in range(args.warmup):
+            out = t.train_step(batch)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = t.train_step(batch)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
+        return dt, passes, float(out["total"])
+
+    other = "deterministic" if args.variant == "as_executed" else "as_executed"
+    dt, passes, loss = timed(args.variant)
+    second = None if args.single_variant else timed(other)
+    set_variant(args.variant)
+    # roofline leg: the SAME workload for a few more steps with per-launch events around the dominant kernel and the attention
+    # launches.  The side stream is switched off here so that the events bracket only the kernel (with two streams the elapsed time
     # between events includes waiting for the other stream's kernels); this is what rocprofv3 reports as duration.
-    probe = None
+    probe = attn = None
     if not args.no_probe and rank == 0 and world == 1:
         t.visual_side_stream = False
         t.train_step(batch)
         torch.cuda.synchronize()
         ops.GemmProbe.start(L.AV_BF16 if args.precision == "bf16" else L.AV_F32, L.A_ROWMAJOR, L.B_NK, True)
+        ops.AttnProbe.start()
         probe_steps = min(3, args.steps)
         for _ in range(probe_steps):
-            out = t.train_step(batch)
+            t.train_step(batch)
         torch.cuda.synchronize()
         probe = ops.GemmProbe.stop()
         probe["steps"] = probe_steps
-    loss = float(out["total"])
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+        attn = attention_report(ops.AttnProbe.stop(), probe_steps)
 
     if rank == 0:
-        ms = 1000.0 * dt / args.steps
-        utt_s = args.batch * world / (dt / args.steps)
-        fl = flops_per_utt(cfg, T_audio, T_v, args.audio_passes)
+        def line(dt_, passes_, variant):
+            fl = flops_per_utt(cfg, T_audio, T_v, passes_)
+            if variant == "as_executed":       # LayerDrop skips a layer (forward and backward) with probability 0.1: expected executed work
+                Hh, Ii = cfg["hidden_size"], cfg["intermediate_size"]
+                lin = (8.0 * Hh * Hh + 4.0 * Hh * Ii) * T_enc; att = 4.0 * T_enc * T_enc * Hh
+                ld = HF_REGULARIZERS["layerdrop"]
+                fl -= passes_ * ld * (24 * (lin + att) + 14 * (lin + 2 * att) + 4 * (2 * lin + 2 * att))
+            utt = args.batch * world / (dt_ / args.steps)
+            return {"value": round(utt, 3), "ms_per_step": round(1000.0 * dt_ / args.steps, 3), "audio_passes": passes_,
+                    "wav2vec2_regularizers": "hf-defaults (dropout 0.1, LayerDrop 0.1, SpecAugment 0.05)" if variant == "as_executed" else "off (deterministic parity configuration)",
+                    "algorithmic_gflop_per_utt": round(fl / 1e9, 1), "step_tflops": round(fl * utt / 1e12, 1),
+                    "step_frac_of_mfma_peak": round(fl * utt / 1e12 / peak, 4)}
         peak = 2500.0 if args.precision == "bf16" else 157.3
+        head = line(dt, passes, args.variant)
         roof = None
         if probe and probe["records"]:
             tot_ms = sum(r[0].elapsed_time(r[1]) for r in probe["records"])
             tot_fl = sum(r[2] for r in probe["records"])
             tot_by = sum(r[3] for r in probe["records"])
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")       # separate rocprofv3 --pmc passes (see file)
-            if args.precision == "bf16" and os.path.exists(pmc):
-                tb = tl = 0                                                     # launch-weighted over the two tilings of the family
-                for kname, kv in json.load(open(pmc))["kernels"].items():
-                    if "gemm_nt_bf16_kernel<128, false, false, false>" in kname or "gemm_nt_bf16_v2_kernel" in kname:
-                        tb += kv["launches"] * (kv["fetch_bytes_per_launch"] + kv["write_bytes_per_launch"]); tl += kv["launches"]
-                traffic = round(tb / tl) if tl else None
+            traffic = tsrc = None
+            for cand in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):       # separate rocprofv3 --pmc passes (see file)
+                pmc = os.path.join(ROOT, "profiles", cand)
+                if args.precision == "bf16" and os.path.exists(pmc):
+                    tb = tl = 0                                                         # launch-weighted over the tilings of the family
+                    for kname, kv in json.load(open(pmc))["kernels"].items():
+                        if "gemm_nt_bf16_kernel<128, false, false, false>" in kname or "gemm_nt_bf16_v2_kernel" in kname or "gemm_nt_bf16_v3_kernel" in kname:
+                            tb += kv["launches"] * (kv["fetch_bytes_per_launch"] + kv["write_bytes_per_launch"]); tl += kv["launches"]
+                    traffic, tsrc = (round(tb / tl) if tl else None), cand
+                    break
             n = len(probe["records"])
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_kernel<128,false,false,false> + gemm_nt_bf16_v2_kernel (K >= 2048)" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>") + " (row-major NT products: every nn.Linear forward, dX through cached W^T, strided conv1d; the k-major dW / trained-layer dX launches run a sibling instantiation and are not in this figure)",
+            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16 family (row-major NT products: every nn.Linear forward, dX through cached W^T, strided conv1d)" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                    "traffic_note": "HBM-side bytes per launch from profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
+                    "traffic_note": f"HBM-side bytes per launch from profiles/{tsrc} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                     "algorithmic_bytes_per_launch": round(tot_by / n),
                     "launches_per_step": n // probe["steps"], "measured": "same workload, extra steps after the timed region, single stream", "avg_launch_us": round(1000.0 * tot_ms / n, 2),
                     "algorithmic_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
-        res = {"metric": "utterances/sec (4 s clip, 25 fps 96x96 lip), full training step", "value": round(utt_s, 3),
-               "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        res = {"metric": "utterances/sec (4 s clip, 25 fps 96x96 lip) at batch 64, full training step", "value": head["value"],
+               "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-               "config": {"workload": f"configs[1]: batch {args.batch}/GPU x {args.seconds:g} s (T_audio {T_audio}, T_enc {T_enc}, "
-                                      f"{T_v} lip frames 96x96 x 2 speakers), wav2vec2-large + ResNet-18 + fusion BiLSTM + CTC, "
-                                      "fwd+bwd+Adam, random-init weights",
-                          "global_batch": args.batch * world, "parallelism": f"dp{world}", "audio_passes": args.audio_passes, "wav2vec2_regularizers": "hf-defaults" if args.regularize else "off (deterministic)",
+               "config": {"workload": f"BASELINE metric configuration (= configs[3]'s per-GPU batch): batch {args.batch}/GPU x {args.seconds:g} s "
+                                      f"(T_audio {T_audio}, T_enc {T_enc}, {T_v} lip frames 96x96 x 2 speakers), wav2vec2-large + ResNet-18 + fusion "
+                                      "BiLSTM + CTC + contrastive, fwd+bwd+Adam, random-init weights",
+                          "variant": args.variant, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                          "audio_passes": head["audio_passes"], "wav2vec2_regularizers": head["wav2vec2_regularizers"],
                           "lambda_contrastive": args.lambda_, "final_loss": round(loss, 4),
-                          "algorithmic_gflop_per_utt": round(fl / 1e9, 1),
-                          "step_tflops": round(fl * utt_s / 1e12, 1), "step_frac_of_mfma_peak": round(fl * utt_s / 1e12 / peak, 4)},
+                          "algorithmic_gflop_per_utt": head["algorithmic_gflop_per_utt"],
+                          "step_tflops": head["step_tflops"], "step_frac_of_mfma_peak": head["step_frac_of_mfma_peak"]},
                "roofline": roof}
+        if second is not None:
+            res["other_variant"] = dict(line(second[0], second[1], other), variant=other, steps=args.steps, warmup=args.warmup)
+        if attn is not None:
+            res["attention"] = attn
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.seconds)
         print(json.dumps(res), flush=True)

@@ -11,33 +11,43 @@ import torch
 import torch.nn as nn
 
 from ..utils import init as _init
-from .w2v2 import Wav2Vec2ModelHIP, load_local_config, w2v2_apply
+from .w2v2 import Wav2Vec2ModelHIP, load_local_config, load_local_weights, w2v2_apply
 
 
 class AudioEncoder(nn.Module):
     """model/encoder.py:80-100.  ``model_name`` is a LOCAL HF wav2vec2 directory (config.json [+ model.safetensors]);
     a dict is accepted as an in-memory config (random init).  Returns (last_hidden_state, mean(hidden_states[6:10]))."""
 
-    def __init__(self, model_name: Union[str, dict] = "kresnik/wav2vec2-large-xlsr-korean", freeze: bool = True, seed: int = 2):
+    def __init__(self, model_name: Union[str, dict] = "kresnik/wav2vec2-large-xlsr-korean", freeze: bool = True, seed: int = 2,
+                 random_init: bool = False):
         super().__init__()
         weights = None
-        if isinstance(model_name, dict):
+        if isinstance(model_name, dict):                      # in-memory config: seeded random weights (tests, benchmarks)
             cfg = model_name
         elif os.path.isdir(model_name):
             cfg = load_local_config(model_name)
-            st = os.path.join(model_name, "model.safetensors")
-            if os.path.exists(st):
-                from safetensors.torch import load_file
-                weights = load_file(st)
+            weights = load_local_weights(model_name)
+            if weights is None and not random_init:
+                raise FileNotFoundError(
+                    f"AudioEncoder: {model_name!r} holds neither model.safetensors nor pytorch_model.bin; training would start from an "
+                    "untrained wav2vec2 — pass random_init=True if that is intended")
         else:
             raise FileNotFoundError(
                 f"AudioEncoder: {model_name!r} is not a local directory; pretrained checkpoints cannot be fetched "
                 "(no network) — pass a local HF wav2vec2 directory or a config dict")
         self.model = Wav2Vec2ModelHIP(cfg)
+        if weights is not None and not cfg.get("conv_bias", True):
+            # conv_bias=False checkpoints have no feature-extractor conv biases: the kernels always add one, so they are zeros
+            for i, c in enumerate(cfg["conv_dim"]):
+                weights.setdefault(f"feature_extractor.conv_layers.{i}.conv.bias", torch.zeros(c))
         sd = _init.w2v2_state_dict(cfg, seed=seed, prefix="") if weights is None else weights
-        missing = self.model.load_state_dict(sd, strict=False)
-        if weights is not None and [k for k in missing.missing_keys if k != "masked_spec_embed"]:
-            raise KeyError(f"AudioEncoder: checkpoint lacks {missing.missing_keys[:5]}")
+        res = self.model.load_state_dict(sd, strict=False)
+        if weights is not None:
+            # masked_spec_embed is absent from checkpoints saved with both SpecAugment probabilities at 0 (hf:1252-1253)
+            missing = [k for k in res.missing_keys if k != "masked_spec_embed"]
+            if missing or res.unexpected_keys:
+                raise KeyError(f"AudioEncoder: checkpoint does not match the architecture of config.json: missing {missing[:5]}, "
+                               f"unexpected {list(res.unexpected_keys)[:5]}")
         self.output_dim = self.model.config.hidden_size
         if freeze:
             for p in self.model.parameters():

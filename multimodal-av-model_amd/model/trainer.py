@@ -101,6 +101,13 @@ class MultimodalTrainer:
         self.reducer = reducer
         if reducer is not None:
             self.optimizer.grad_scale = 1.0 / reducer.world
+            if reducer.world > 1:
+                # the collective schedule must not depend on the rank: LayerDrop decisions come from a generator seeded identically
+                # everywhere (every rank draws once per layer and pass), dropout masks from one seeded per rank
+                import torch.distributed as dist
+                m = self.audio_encoder.model
+                m.layerdrop_generator = torch.Generator().manual_seed(0x5EED1A7E)
+                m.dropout_generator = torch.Generator().manual_seed(0xD120 + 7919 * dist.get_rank(reducer.group))
             self.audio_encoder.model.grad_ready = reducer.reduce_async
             self.audio_encoder.model.grad_wait = reducer.wait
             self._head_params = [p for m in (self.decoder1, self.fusion_module) for n, p in m.named_parameters()
@@ -169,7 +176,8 @@ class MultimodalTrainer:
         il = torch.cat([self._fusion_lengths_host(cpu_batch["mask1"], T_enc, Tv), self._fusion_lengths_host(cpu_batch["mask2"], T_enc, Tv)])
         tl = torch.cat([cpu_batch["text1_lengths"].cpu().long(), cpu_batch["text2_lengths"].cpu().long()])
         return {"_counts1": self._class_counts(cpu_batch["mask1"], T_enc), "_counts2": self._class_counts(cpu_batch["mask2"], T_enc),
-                "_ctc_input_lengths": il, "_ctc_target_lengths": tl}
+                "_ctc_input_lengths": il, "_ctc_target_lengths": tl,
+                "_same_padding": bool(torch.equal(cpu_batch["mask1"] != 3, cpu_batch["mask2"] != 3))}
 
     def forward_losses(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """model/trainer.py:66-119 for one batch; everything stays on the device."""
@@ -192,6 +200,14 @@ class MultimodalTrainer:
             cfg = getattr(self.audio_encoder.model, "cfg", {})
             knobs = ("hidden_dropout", "attention_dropout", "activation_dropout", "feat_proj_dropout", "layerdrop", "mask_time_prob")
             passes = 2 if (self.audio_encoder.training and any(cfg.get(k, 0) > 0 for k in knobs)) else 1
+        if passes == 1:
+            # one pass stands for both only if the two padding patterns are the same (they are for the reference's dataset, SURVEY
+            # §0.3; a batch from elsewhere falls back to two passes).  Host copy when available, otherwise one device comparison
+            same = batch.get("_same_padding")
+            if same is None:
+                same = bool(torch.equal(batch["mask1"] != 3, batch["mask2"] != 3))
+            if not same:
+                passes = 2
         if passes == 2:
             self.audio_encoder.model._feat_cache = {}              # both passes read the same waveform: one conv feature-extractor run
         try:
@@ -263,6 +279,8 @@ class MultimodalTrainer:
     def train_step(self, batch) -> Dict[str, torch.Tensor]:
         """zero_grad -> forward -> backward (-> bucketed all-reduce) -> Adam; no host sync."""
         self.optimizer.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            self._head_done = False
         out = self.forward_losses(batch)
         out["total"].backward()
         if self.reducer is not None:
@@ -276,6 +294,10 @@ class MultimodalTrainer:
         return out
 
     def _reduce_head(self):
+        # once per step: with two audio passes the wav2vec2 backward (and this hook) runs twice, and p.grad are by then views of the
+        # already reduced bucket (a second all-reduce would sum them world_size times)
+        if self._head_done:
+            return
         hp = [p for p in self._head_params if p.grad is not None]
         for p, v in zip(hp, self.reducer.reduce_async([p.grad for p in hp])):
             p.grad = v
@@ -295,6 +317,9 @@ class MultimodalTrainer:
                           f"Total: {out['total'].item():.4f}", flush=True)
             except Exception as e:       # model/trainer.py:162-164: skip the batch, keep going
                 print(f"Error at batch {batch_idx}: {e}", flush=True)
+                if self.reducer is not None and self.reducer.world > 1:
+                    # data parallel: a rank that skips a batch no longer issues the collectives its peers are waiting in
+                    raise
                 continue
         return total_loss / max(1, len(dataloader))
 

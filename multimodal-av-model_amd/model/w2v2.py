@@ -125,6 +125,11 @@ class Wav2Vec2ModelHIP(nn.Module):
         self.grad_ready = None
         self.grad_wait = None
         self.grad_pre = None            # called when this model's backward starts (the trainer reduces the head gradients there)
+        # host RNG sources of the train-mode regularisers.  None = torch's global generator (what HF uses).  Under data parallelism the
+        # trainer installs a LayerDrop generator that is IDENTICAL on every rank (a dropped trainable layer issues no gradient bucket, so
+        # ranks that disagreed would issue different collective sequences) and a dropout-seed generator that DIFFERS per rank
+        self.layerdrop_generator = None
+        self.dropout_generator = None
 
     # ---- parameter access ------------------------------------------------------------------------------------
     def P(self, name: str) -> Tensor:
@@ -229,7 +234,7 @@ class Wav2Vec2ModelHIP(nn.Module):
         ac_p = sc["activation_dropout"] if tm else 0.0
         fp_p = sc["feat_proj_dropout"] if tm else 0.0
         ld_p = sc["layerdrop"] if tm else 0.0
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (hd_p or at_p or ac_p or fp_p) else 0
+        seed = int(torch.randint(0, 2 ** 62, (1,), generator=self.dropout_generator).item()) if (hd_p or at_p or ac_p or fp_p) else 0
         # the conv feature extractor is frozen and has no stochastic op, so two passes over the SAME waveform tensor (the reference's
         # audio_encoder(audio, mask1) / (audio, mask2), model/trainer.py:88-96) share its output while the trainer holds the window open
         fc = getattr(self, "_feat_cache", None)
@@ -284,7 +289,7 @@ class Wav2Vec2ModelHIP(nn.Module):
                 ops.axpby(0.25, h, 1.0, mid)                                             # model/encoder.py:97-99
             p = f"encoder.layers.{li}."
             keep_ctx = save and li >= first
-            if ld_p > 0 and float(torch.rand([])) < ld_p:                                # LayerDrop (hf:774-789): identity layer
+            if ld_p > 0 and float(torch.rand([], generator=self.layerdrop_generator)) < ld_p:    # LayerDrop (hf:774-789): identity layer
                 if keep_ctx:
                     saved[li] = "skipped"
                 continue
@@ -464,4 +469,41 @@ def load_local_config(path: str) -> dict:
                        mask_time_prob=0.05, mask_time_length=10, mask_time_min_masks=2, mask_feature_prob=0.0, apply_spec_augment=True)
     for k, v in hf_defaults.items():          # a real checkpoint trains with its own regularisation settings
         out[k] = c.get(k, v)
+    out["conv_bias"] = bool(c.get("conv_bias", False))       # HF default False; XLSR-53 checkpoints have True
     return out
+
+
+_DROP_PREFIXES = ("lm_head.", "quantizer.", "project_hid.", "project_q.", "dropout_features.")
+
+
+def remap_hf_keys(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """State-dict keys of a local HF wav2vec2 checkpoint -> the ``Wav2Vec2Model`` names this module uses, the way
+    ``from_pretrained`` resolves them (model/encoder.py:83 loads a ``Wav2Vec2ForCTC`` fine-tune into ``Wav2Vec2Model``):
+    the ``wav2vec2.`` prefix of task heads is stripped, head / pre-training tensors (``lm_head.*``, ``quantizer.*``,
+    ``project_hid.*``, ``project_q.*``) are dropped, and the legacy weight-norm names ``weight_g`` / ``weight_v`` of the
+    positional convolution become ``parametrizations.weight.original0`` / ``original1``."""
+    out: Dict[str, Tensor] = {}
+    for k, v in sd.items():
+        if k.startswith("wav2vec2."):
+            k = k[len("wav2vec2."):]
+        if k.startswith(_DROP_PREFIXES):
+            continue
+        if k.endswith("pos_conv_embed.conv.weight_g"):
+            k = k[:-len("weight_g")] + "parametrizations.weight.original0"
+        elif k.endswith("pos_conv_embed.conv.weight_v"):
+            k = k[:-len("weight_v")] + "parametrizations.weight.original1"
+        out[k] = v
+    return out
+
+
+def load_local_weights(path: str) -> Optional[Dict[str, Tensor]]:
+    """Tensors of a LOCAL HF directory: ``model.safetensors`` or ``pytorch_model.bin`` (``weights_only=True``: nothing from the
+    file is executed).  None if the directory holds neither."""
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        return remap_hf_keys(load_file(st))
+    pt = os.path.join(path, "pytorch_model.bin")
+    if os.path.exists(pt):
+        return remap_hf_keys(torch.load(pt, map_location="cpu", weights_only=True))
+    return None

@@ -62,6 +62,33 @@ class GemmProbe:
         return a
 
 
+class AttnProbe:
+    """Optional live timing of the attention launches with events on the launch stream (bench.py ``attention`` report).
+    Records (start, end, tag, flops, bytes); tag = "fwd"/"bwd" + head_dim (64 = wav2vec2 self-attention K7, 128 = fusion K17)."""
+    active = None
+
+    @classmethod
+    def start(cls):
+        cls.active = []
+
+    @classmethod
+    def stop(cls):
+        a, cls.active = cls.active, None
+        return a
+
+
+def _probed(tag, flops, nbytes, fn):
+    pr = AttnProbe.active
+    if pr is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    pr.append((e0, e1, tag, float(flops), float(nbytes)))
+    return r
+
+
 def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
          a_mode: int = L.A_ROWMAJOR, b_mode: int = L.B_NK, bias: Optional[Tensor] = None, act: int = L.ACT_NONE,
          R: Optional[Tensor] = None, ldr: int = 0, aux: Optional[Tensor] = None, C2: Optional[Tensor] = None,
@@ -350,9 +377,11 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, klen: Optional[Tensor], scale
     o = torch.empty((B, Tq, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if need_lse else None
     dp, dseed, dstream = (float(drop[0]), int(drop[1]), int(drop[2])) if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
-    L.check(L.lib().av_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), dt(q), B, H, Tq, Tk, D,
-                                     q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                     o.stride(0), o.stride(1), ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_fwd")
+    es = q.element_size()
+    _probed(f"fwd{D}", 4.0 * B * H * Tq * Tk * D, B * H * D * es * (2 * Tq + 2 * Tk),
+            lambda: L.check(L.lib().av_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), dt(q), B, H, Tq, Tk, D,
+                                                     q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                                     o.stride(0), o.stride(1), ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_fwd"))
     return o, lse
 
 
@@ -372,8 +401,10 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: T
         _chk_view(o, "o")
         st = (C.c_longlong * 16)(*[x for t in (q, k, v, o, do, dq, dk, dv) for x in (t.stride(0), t.stride(1))])
         delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
-        L.check(L.lib().av_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                                         B, H, Tq, Tk, D, st, ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_bwd")
+        es = q.element_size()
+        _probed(f"bwd{D}", 10.0 * B * H * Tq * Tk * D, B * H * D * es * (4 * Tq + 4 * Tk),
+                lambda: L.check(L.lib().av_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                                         B, H, Tq, Tk, D, st, ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_bwd"))
         return
     ld = (Tk + 7) // 8 * 8
     dev = q.device

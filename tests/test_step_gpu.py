@@ -116,18 +116,7 @@ def test_step_fp32_vs_reference_fixture(name, cfg_name):
     assert int(vs["frontend3D.1.num_batches_tracked"]) == int(fx["bn_num_batches_tracked"])
 
 
-def test_step_bf16_reported_error():
-    """Perf mode: same step in bf16; the error against the reference fixture is measured and bounded loosely."""
-    fx = np.load(os.path.join(GOLD, "tiny.npz"))
-    init = pkg("utils.init"); synth = pkg("dataset.synthetic")
-    t = build(init.W2V2_TINY, "bf16")
-    batch = synth.make_batch(int(fx["batch"]), float(fx["seconds"]), seed=int(fx["seed_batch"]), ragged=False)
-    t.visual_encoder.train()
-    out = t.train_step(batch)
-    e_lp = maxdiff(out["log_probs1"].detach().cpu(), fx["train_log_probs1"])
-    e_loss = abs(float(out["total"]) - float(fx["train_total"]))
-    print(f"bf16 step: max|dlogp| = {e_lp:.4f}, |dloss| = {e_loss:.4f} (loss {float(fx['train_total']):.3f})")
-    assert e_lp < 0.5 and e_loss < 0.5
+# the bf16 (benchmarked) mode is gated in tests/test_sizes_gpu.py: tiny + full-size c1 fixtures and the BASELINE batch sizes
 
 
 def test_host_metadata_gives_the_same_step():
