@@ -90,24 +90,42 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// ---- counter-based RNG (Philox4x32-10) for dropout: the mask of element `idx` of stream `stream` under `seed` is a pure
-// function of (seed, stream, idx), so the backward pass regenerates exactly the forward's mask without storing it.
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+// ---- counter-based RNG (Philox2x32-10, Salmon et al. SC'11) for dropout: the mask of element `idx` of stream `stream` under `seed`
+// is a pure function of (seed, stream, idx), so the backward pass regenerates exactly the forward's mask without storing it.
+// One Philox block (64-bit counter = idx / 4, 32-bit key mixed from seed and stream) yields 64 bits = FOUR 16-bit uniforms, one per
+// element of an aligned group of 4: one multiply pair per round and element group (the 4x32 form spent two), and the drop
+// probability is resolved to 2^-16.
+__device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned stream) {
+    unsigned h = (unsigned)seed * 0x9E3779B1u;
+    h ^= (unsigned)(seed >> 32) * 0x85EBCA77u;
+    h ^= (stream + 0x165667B1u) * 0xC2B2AE3Du;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h;
+}
+__device__ __forceinline__ void philox2x32_10(unsigned c0, unsigned c1, unsigned k, unsigned& o0, unsigned& o1) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        const unsigned long long pr = (unsigned long long)0xD256D193u * c0;
+        const unsigned n0 = (unsigned)(pr >> 32) ^ k ^ c1;
+        c1 = (unsigned)pr; c0 = n0;
+        k += 0x9E3779B9u;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    o0 = c0; o1 = c1;
 }
-// uniform in [0,1) for element idx (one Philox block per 4 consecutive elements)
+// the four 16-bit uniforms (as floats in [0,1)) of the aligned group that starts at element idx4 (a multiple of 4)
+__device__ __forceinline__ void drop_uniform4(unsigned long long seed, unsigned stream, unsigned long long idx4, float (&u)[4]) {
+    const unsigned long long blk = idx4 >> 2;
+    unsigned o0, o1;
+    philox2x32_10((unsigned)blk, (unsigned)(blk >> 32), drop_key(seed, stream), o0, o1);
+    u[0] = (float)(o0 & 0xFFFFu) * (1.0f / 65536.0f); u[1] = (float)(o0 >> 16) * (1.0f / 65536.0f);
+    u[2] = (float)(o1 & 0xFFFFu) * (1.0f / 65536.0f); u[3] = (float)(o1 >> 16) * (1.0f / 65536.0f);
+}
+// uniform in [0,1) for element idx
 __device__ __forceinline__ float drop_uniform(unsigned long long seed, unsigned stream, unsigned long long idx) {
-    unsigned o[4];
-    const unsigned long long blk = idx >> 2;
-    philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
-    return (float)(o[idx & 3] >> 8) * (1.0f / 16777216.0f);
+    float u[4];
+    drop_uniform4(seed, stream, idx & ~3ull, u);
+    const int e = (int)(idx & 3);
+    return e == 0 ? u[0] : e == 1 ? u[1] : e == 2 ? u[2] : u[3];
 }
 // multiplier of element idx: 0 (dropped) or 1/(1-p)
 __device__ __forceinline__ float drop_mult(unsigned long long seed, unsigned stream, unsigned long long idx, float p, float inv_keep) {
@@ -119,11 +137,10 @@ __device__ __noinline__ float drop_mult_call(unsigned long long seed, unsigned s
 }
 // 4 consecutive elements starting at a multiple of 4 (one Philox call)
 __device__ __forceinline__ void drop_mult4(unsigned long long seed, unsigned stream, unsigned long long idx4, float p, float inv_keep, float (&m)[4]) {
-    unsigned o[4];
-    const unsigned long long blk = idx4 >> 2;
-    philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+    float u[4];
+    drop_uniform4(seed, stream, idx4, u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = ((float)(o[i] >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.f;
+    for (int i = 0; i < 4; ++i) m[i] = u[i] >= p ? inv_keep : 0.f;
 }
 
 static inline int av_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -43,17 +43,6 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, long
 }
 
 
-// ONE LDS-DMA wave instruction of an operand tile (for kernels that spread a stage's instructions over their MFMA groups): rows 8 ins .. 8 ins + 7 (128 B each, chunk XOR-swizzled with the row)
-__device__ __forceinline__ void stage_one(const bf16_t* __restrict__ base, long long ld, int row0, int nrows, int k0, char* tile, int ins, int lane) {
-    const int sub = lane >> 3, pch = lane & 7;
-    int gr = row0 + ins * 8 + sub;
-    if (gr > nrows - 1) gr = nrows - 1;
-    const bf16_t* src = base + (long long)gr * ld + k0 + ((pch ^ sub) << 3);
-    const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(ins * 1024));
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
-}
-
-
 // ---- k-major operands (element (k, c) at base[k * ld + c]: the A of dW = dY^T X, the B of dX = dY W) --------------------
 // Tile = 64 k-rows x 128 columns (256-B rows), filled by LDS-DMA (a wave instruction = 4 rows); MFMA fragments come out of it
 // with ds_read_b64_tr_b16: a 16-lane group reads 4 k-rows x 16 columns and receives them column-major, so lane (c = lane & 15,
@@ -631,38 +620,144 @@ __global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v3 (EXPERIMENTAL, off by default; AVAMD_GEMM_V3 = 1: N >= 4096 with K < 2048, 2: every NT product): 256 x 256 x 64 tile, 8 wavefronts
-// as 2 (M) x 4 (N) with 128 x 64 each (128 accumulator registers), two LDS stages of 64 KiB.
-// Measured (8192^3, random operands; core-clock stamps: tools/v3_stamps.cpp):
-//   * two plain stages, the 8 LDS-DMA instructions of a wavefront issued in one burst after the barrier: 1.18 PF/s.  Stamps: the
-//     data wait is ~30 clocks (the DMA has long landed) but the ISSUE of the burst holds a wavefront 600-1300 clocks (64 instructions x
-//     8 lines queue at the CU's address unit) with the MFMA pipes idle: 3290 clocks per K-tile against 2048 of MFMA work;
-//   * the same instructions spread over the MFMA groups: 2650 clocks per K-tile, 1.25 PF/s - 77 % MFMA utilisation; the clock under
-//     this load is ~1.55 GHz (2650 clocks in 1.72 us), so the attainable peak is ~1.6 PF/s, not 2.5;
-//   * + rolling fragment window with the stage hand-over inside the MFMA block (this form): 1.22 PF/s at 8192^3, 67 us on
-//     6368 x 4096 x 1024 (128 x 128 kernel: 72, previous form: 69); wavefronts 0-3 still wait ~700 clocks at the barrier for 4-7
-//     (issue priority on the shared SIMD);
-//   * BK = 32 with 64-B rows and a four-stage ring: 1.09-1.10 PF/s whatever the barrier structure (mid-step hand-over, staggered
-//     wavefront groups, s_setprio): a 64-B row costs a full line request; a ring of ten 16-KiB half-tiles with burst issue: 1.05;
-//   * 128 x 128 kernel 1.15-1.22, 256 x 128 three-stage 1.2 (spreading its DMA issue changed nothing: two of its three stages are
-//     already in flight), vendor library 256 x 256 stream-K 1.55.
+// v4: 256 x 256 x 64 tile with HALF-TILE granularity (the guide's "256^2 8-phase" schedule): 8 wavefronts as 2 (M) x 4 (N); the block
+// tile is four 128 x 128 quadrants (A halves 0/1 x B halves 0/1) and every wavefront owns a 64 x 32 piece of EACH quadrant
+// (128 accumulator registers).  A K-tile is four phases, one quadrant each: (A0,B0) (A0,B1) (A1,B1) (A1,B0); a phase is
+//     { fragment reads of the half-tile(s) the quadrant adds (12 / 4 / 8 / 4 ds_read_b128) ; 2 LDS-DMA instructions = ONE 16-KiB
+//       half-tile of the prefetch ; s_barrier ; lgkmcnt(0) ; 16 MFMAs ; s_barrier }.
+// LDS = 2 K-tiles x 4 half-tile slots (A0, B1, A1, B0 in issue order) = 128 KiB.  The DMA runs 6 half-tiles ahead of the phase that
+// issues it: phase p of K-tile t issues half-tile 4t+p+6, i.e. (t+1: A1), (t+1: B0), (t+2: A0), (t+2: B1) - every slot is re-filled
+// TWO phases after its last fragment read (A0: read in phase 0, B1: 1, A1: 2, B0: 0 and 3), which is what the staggered wavefront
+// groups need (below), and ONE counted wait per K-tile (vmcnt(4) in phase 3: everything but the two youngest half-tiles has landed =
+// all of K-tile t+1) keeps the queue from ever draining inside the loop.
+// Stagger: wavefronts 4-7 run one barrier behind 0-3 (one extra s_barrier at entry, balanced at exit), so on every SIMD one wavefront
+// is in its MFMA segment while its partner issues reads / DMA: the matrix pipe sees back-to-back 16-MFMA clusters.
+// RAW: a half-tile is read at the earliest one phase after the counted wait + barrier that retired it.  WAR: the lagging group's
+// reads of phase c complete (lgkmcnt(0)) inside the leading group's phase c+1 read segment, hence the two-phase refill distance.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int V3_BM = 256, V3_BN = 256, V3_NT = 512;
-constexpr int V3_STAGE = (V3_BM + V3_BN) * BK * 2;          // 65 536 B
-constexpr int V3_CLD = V3_BN + 4;
-constexpr int V3_EPI = 128 * V3_CLD * 4;                    // 133 120 B
-constexpr int V3_LDS = 2 * V3_STAGE > V3_EPI ? 2 * V3_STAGE : V3_EPI;
+constexpr int V4_BM = 256, V4_BN = 256, V4_NT = 512;
+constexpr int V4_HALF = 128 * BK * 2;                       // 16 384 B: one half-tile slot (128 rows x 128 B)
+constexpr int V4_KT = 4 * V4_HALF;                          // 65 536 B per K-tile
+constexpr int V4_CLD = V4_BN + 4;
+constexpr int V4_EPI = 128 * V4_CLD * 4;                    // 133 120 B
+constexpr int V4_LDS = 2 * V4_KT > V4_EPI ? 2 * V4_KT : V4_EPI;
 
-__global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
+// Tail jobs of the v4 grid: ONE 128 x 128 quadrant of a 256 x 256 tile per workgroup (same wavefront layout: 2 x 4, 64 x 32 each, 32
+// accumulator registers).  When the tile count leaves a short last round (R = tiles mod 256 <= 128), those R tiles are cut into 4 R
+// quadrant jobs that fill the chip instead of R of 256 CUs working a whole tile time.  A K-tile is ONE phase here: an A half-tile and
+// a B half-tile per K-tile in a ring of four 32-KiB slots, refilled two phases after the last read (staggered groups, as above), the
+// DMA two K-tiles ahead, vmcnt(4) per phase.
+__device__ __forceinline__ void v4_quadrant_job(const av_gemm_args& p, const FastFlags& fl, char* smem, const bf16_t* A, const bf16_t* B,
+                                                const int m0, const int n0, const long long cbase, const float* R, const float* bias) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = __builtin_amdgcn_readfirstlane(w >> 2), wc = w & 3;
+    const int r = lane & 15, g = lane >> 4;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = p.K / BK;
+    auto issue = [&](int t) {
+        char* slot = smem + (t & 3) * (2 * V4_HALF);
+        stage_rows<2>(A, p.lda, m0, p.M, t * BK, slot, w, lane);
+        stage_rows<2>(B, p.ldb, n0, p.N, t * BK, slot + V4_HALF, w, lane);
+    };
+    issue(0);
+    if (nk > 1) { issue(1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    const int sw = r & 7;
+    const int ch0 = (g ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
+    const int a_row = (wr * 64 + r) * 128, b_row = V4_HALF + (wc * 32 + r) * 128;
+    bf16x8 fa[4][2], fb[2][2];
+    for (int t = 0; t < nk; ++t) {
+        const char* kb = smem + (t & 3) * (2 * V4_HALF);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = *(const bf16x8*)(kb + b_row + j * 2048 + ch0);
+            fb[j][1] = *(const bf16x8*)(kb + b_row + j * 2048 + ch1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *(const bf16x8*)(kb + a_row + i * 2048 + ch0);
+            fa[i][1] = *(const bf16x8*)(kb + a_row + i * 2048 + ch1);
+        }
+        if (t + 2 < nk) { issue(t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }     // K-tile t+1 has landed, t+2 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    constexpr int QLD = 128 + 4;
+    float* cs = (float*)smem;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                cs[(wr * 64 + i * 16 + 4 * g + e) * QLD + wc * 32 + j * 16 + r] = acc[i][j][e] * p.alpha;
+    __syncthreads();
+    constexpr int CPR = 128 / 8;
+    float bv[8];
+    {
+        const int gnt = n0 + (tid % CPR) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (bias && gnt + e < p.N) ? bias[gnt + e] : 0.f;
+    }
+    for (int it = 0; it < 128 * CPR / V4_NT; ++it) {
+        const int id = it * V4_NT + tid;
+        const int row = id / CPR, cc = (id % CPR) * 8;
+        const int gm = m0 + row, gn = n0 + cc;
+        if (gm >= p.M || gn >= p.N) continue;
+        float v[8];
+        const f32x4 v0 = *(const f32x4*)(cs + row * QLD + cc), v1 = *(const f32x4*)(cs + row * QLD + cc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
+        const bool full = gn + 8 <= p.N;
+        const long long off = cbase + (long long)gm * p.ldc + gn;
+        epilogue_store(p, fl, v, off, gm, gn, full, R);
+    }
+}
+
+__global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl, const int nfull) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
-    const int wrow = (w >> 2) * 128, wcol = (w & 3) * 64;
+    const int wr = __builtin_amdgcn_readfirstlane(w >> 2), wc = w & 3;
     const int r = lane & 15, g = lane >> 4;
-    const int nwg = nbM * nbN;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    // jobs: blocks [0, nfull) are whole tiles, blocks nfull + 4 i + q the four quadrants of tile nfull + i (the short last round).
+    // Each section gets the XCD-aware bijective remap of its own id range; tile ids are grouped 4 row panels x all column panels.
+    const int ntile = nbM * nbN;
+    int bid = blockIdx.x, quad = -1;
+    if (bid < nfull) {
+        const int q = nfull >> 3, rem = nfull & 7, xcd = bid & 7, slot = bid >> 3;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    } else {
+        const int nq = 4 * (ntile - nfull);
+        int j = bid - nfull;
+        const int q = nq >> 3, rem = nq & 7, xcd = j & 7, slot = j >> 3;
+        j = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+        bid = nfull + (j >> 2);
+        quad = j & 3;
     }
     constexpr int GM = 4;
     const int per_group = GM * nbN;
@@ -670,116 +765,106 @@ __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm
     const int first_m = grp * GM;
     const int gsz = nbM - first_m < GM ? nbM - first_m : GM;
     const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
-    const int m0 = mb * V3_BM, n0 = nb * V3_BN;
+    const int m0 = mb * V4_BM, n0 = nb * V4_BN;
     const int z = blockIdx.z;
     const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
     const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
     const bf16_t* A = (const bf16_t*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
     const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
+    if (quad >= 0) {                                         // block-uniform
+        const int qm = m0 + (quad >> 1) * 128, qn = n0 + (quad & 1) * 128;
+        if (qm < p.M && qn < p.N)
+            v4_quadrant_job(p, fl, smem, A, B, qm, qn, (long long)zo * p.oC + (long long)zi * p.sC, p.R ? p.R + (long long)zi * p.sR : nullptr,
+                            p.bias ? p.bias + (long long)zi * p.sBias : nullptr);
+        return;
+    }
 
-    f32x4 acc[8][4];
+    f32x4 acc[2][2][4][2];                                   // [A half][B half][m-tile][n-tile]
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](int kt, char* buf) {                                   // 8 LDS-DMA instructions per wavefront and stage (8 rows x 128 B each)
-        stage_rows<4>(A, p.lda, m0, p.M, kt * BK, buf, w, lane);
-        stage_rows<4>(B, p.ldb, n0, p.N, kt * BK, buf + V3_BM * BK * 2, w, lane);
-    };
     const int nk = p.K / BK;
-    stage(0, smem);
-    const int sw = r & 7;
-    const int a_off = (wrow + r) * 128, b_off = V3_BM * BK * 2 + (wcol + r) * 128;
-#ifdef AV_V3_STAMPS                                                       // diagnostic build (tools/v3_stamps.cpp): core-clock stamps per loop phase
-    unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_mma = 0;
-#define V3_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime();
-#else
-#define V3_STAMP(x)
-#endif
-    // A K-tile is 16 MFMA groups G = 8 ks + ii (4 MFMAs each: one m-tile x four n-tiles).  Fragments roll through registers: the A
-    // fragment of group G+2 is read at group G (ring of 4), the B fragments of the second K-half at G = 5, and - across the tile
-    // boundary - the next tile's B fragments and first two A fragments at G = 13 .. 15.  The stage hand-over (vmcnt + barrier) sits
-    // in front of G = 13, AFTER every read of this stage (groups 13 .. 15 already hold their fragments), so the barrier skew and the
-    // LDS latency of the first fragments of the next tile are covered by the 12 MFMAs still queued.  The 8 LDS-DMA instructions of
-    // stage kt+1 go out two per group at G = 0 .. 3 (not as one burst: see the stamps above).
-    bf16x8 bA[4], bB[4], ar[4];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                           // stage 0 landed for everyone
+    const int nh = 4 * nk;                                   // half-tiles in issue order: slot j = s & 3 : 0 = A0, 1 = B1, 2 = A1, 3 = B0
+    auto issue = [&](int t, int j) {                         // j is a compile-time constant at every call site
+        char* slot = smem + (t & 1) * V4_KT + j * V4_HALF;
+        if (j == 0) stage_rows<2>(A, p.lda, m0, p.M, t * BK, slot, w, lane);
+        else if (j == 2) stage_rows<2>(A, p.lda, m0 + 128, p.M, t * BK, slot, w, lane);
+        else if (j == 3) stage_rows<2>(B, p.ldb, n0, p.N, t * BK, slot, w, lane);
+        else stage_rows<2>(B, p.ldb, n0 + 128, p.N, t * BK, slot, w, lane);
+    };
+    // prologue: half-tiles 0..5 (K-tile 0 and A0, B1 of K-tile 1)
+    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
+    if (nk > 1) { issue(1, 0); issue(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // K-tile 0 landed for everyone
     asm volatile("" ::: "memory");
-    {
-        const int ch0 = (g ^ sw) << 4;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) bA[jj] = *(const bf16x8*)(smem + b_off + jj * 2048 + ch0);
-        ar[0] = *(const bf16x8*)(smem + a_off + ch0);
-        ar[1] = *(const bf16x8*)(smem + a_off + 2048 + ch0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // wavefronts 4-7 run one barrier behind
+
+    const int sw = r & 7;
+    const int ch0 = (g ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
+    const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
+    bf16x8 fa[4][2], fb[2][2];
+
+#define V4_READ_A(SLOT)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+        fa[i][0] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + a_row + i * 2048 + ch0);                               \
+        fa[i][1] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + a_row + i * 2048 + ch1); }
+#define V4_READ_B(SLOT)                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
+        fb[j][0] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + b_row + j * 2048 + ch0);                               \
+        fb[j][1] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + b_row + j * 2048 + ch1); }
+#define V4_MMA(QA, QB)                                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[QA][QB][i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    asm volatile("" ::: "memory");
+
+    for (int t = 0; t < nk; ++t) {
+        const char* kb = smem + (t & 1) * V4_KT;
+        // phase 0: quadrant (A0, B0)
+        V4_READ_B(3)
+        __builtin_amdgcn_sched_barrier(0);
+        V4_READ_A(0)
+        if (4 * t + 6 < nh) issue(t + 1, 2);
+        V4_MMA(0, 0)
+        // phase 1: (A0, B1)
+        V4_READ_B(1)
+        if (4 * t + 7 < nh) issue(t + 1, 3);
+        V4_MMA(0, 1)
+        // phase 2: (A1, B1)
+        V4_READ_A(2)
+        if (4 * t + 8 < nh) issue(t + 2, 0);
+        V4_MMA(1, 1)
+        // phase 3: (A1, B0); the K-tile's one counted wait: all of K-tile t+1 has landed, the two youngest half-tiles (t+2) may fly
+        V4_READ_B(3)
+        if (4 * t + 9 < nh) { issue(t + 2, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        V4_MMA(1, 0)
     }
-    for (int kt = 0; kt < nk; ++kt) {
-        V3_STAMP(ts0)
-        const bool more = kt + 1 < nk;
-        char* nbuf = smem + ((kt + 1) & 1) * V3_STAGE;
-        const char* sa = smem + (kt & 1) * V3_STAGE + a_off;
-        const char* sb = smem + (kt & 1) * V3_STAGE + b_off;
-        const int chk[2] = {(g ^ sw) << 4, ((4 + g) ^ sw) << 4};
-#pragma unroll
-        for (int G = 0; G < 16; ++G) {
-            const int ks = G >> 3, ii = G & 7;
-            // ---- fragment reads issued at this group
-            if (G <= 11) { const int H = G + 2; ar[H & 3] = *(const bf16x8*)(sa + (H & 7) * 2048 + chk[H >> 3]); }
-            if (G == 12) {
-                ar[14 & 3] = *(const bf16x8*)(sa + 6 * 2048 + chk[1]);
-                ar[15 & 3] = *(const bf16x8*)(sa + 7 * 2048 + chk[1]);
-            }
-            if (G == 5) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) bB[jj] = *(const bf16x8*)(sb + jj * 2048 + chk[1]);
-            }
-            if (G == 13 && more) {                                           // hand-over: every read of stage kt has been issued (and is waited for here)
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                V3_STAMP(tw0)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my LDS-DMA of stage kt+1 landed ...
-                V3_STAMP(tw1)
-                __builtin_amdgcn_s_barrier();                               // ... everyone's; stage kt is free for the DMA of tile kt+2
-                asm volatile("" ::: "memory");
-                V3_STAMP(tw2)
-#ifdef AV_V3_STAMPS
-                st_wait += tw1 - tw0; st_bar += tw2 - tw1;
-#endif
-                const char* nb_ = smem + ((kt + 1) & 1) * V3_STAGE;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) bA[jj] = *(const bf16x8*)(nb_ + b_off + jj * 2048 + chk[0]);
-            }
-            if (G == 14 && more) ar[16 & 3] = *(const bf16x8*)(smem + ((kt + 1) & 1) * V3_STAGE + a_off + chk[0]);
-            if (G == 15 && more) ar[17 & 3] = *(const bf16x8*)(smem + ((kt + 1) & 1) * V3_STAGE + a_off + 2048 + chk[0]);
-            // ---- 4 MFMAs of group G.  bA is overwritten at G = 13 with the NEXT tile's fragments, so the second K-half uses bB only
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[G & 3], ks ? bB[jj] : bA[jj], acc[ii][jj], 0, 0, 0);
-            if (G < 4 && more) {                                             // two LDS-DMA instructions of stage kt+1 behind these MFMAs
-                stage_one(A, p.lda, m0, p.M, (kt + 1) * BK, nbuf, w * 4 + G, lane);
-                stage_one(B, p.ldb, n0, p.N, (kt + 1) * BK, nbuf + V3_BM * BK * 2, w * 4 + G, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#ifdef AV_V3_STAMPS
-        V3_STAMP(ts4)
-        st_mma += ts4 - ts0;
-#endif
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#ifdef AV_V3_STAMPS
-    if (lane == 0 && (w == 0 || w == 5) && p.aux) {                         // [2 wavefronts][5]: wait, barrier, -, whole K-tile, K-tiles
-        unsigned long long* d = (unsigned long long*)p.aux + (w == 0 ? 0 : 5);
-        atomicAdd(d + 0, st_wait); atomicAdd(d + 1, st_bar); atomicAdd(d + 2, st_issue); atomicAdd(d + 3, st_mma); atomicAdd(d + 4, (unsigned long long)nk);
-    }
-#endif
-#undef V3_STAMP
+#undef V4_READ_A
+#undef V4_READ_B
+#undef V4_MMA
+    if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the entry barrier of wavefronts 4-7
 
     float* cs = (float*)smem;
     const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
     const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
     const float* bias = p.bias ? p.bias + (long long)zi * p.sBias : nullptr;
-    constexpr int CPR = V3_BN / 8;                                          // 32 chunks of 8 columns per row
+    constexpr int CPR = V4_BN / 8;                                          // 32 chunks of 8 columns per row
     float bv[8];
     {
         const int gnt = n0 + (tid % CPR) * 8;
@@ -787,25 +872,25 @@ __global__ __launch_bounds__(V3_NT, 2) void gemm_nt_bf16_v3_kernel(const av_gemm
         for (int e = 0; e < 8; ++e) bv[e] = (bias && gnt + e < p.N) ? bias[gnt + e] : 0.f;
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();                                                    // ring / previous half's image is free
-        if ((w >> 2) == half) {
+    for (int half = 0; half < 2; ++half) {                                  // rows half * 128 .. + 127 of the block tile: every wavefront owns 64 x 64 of them
+        __syncthreads();                                                    // stages / previous half's image are free
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        cs[(i * 16 + 4 * g + e) * V3_CLD + wcol + j * 16 + r] = acc[i][j][e] * p.alpha;
-        }
+                        cs[(wr * 64 + i * 16 + 4 * g + e) * V4_CLD + b * 128 + wc * 32 + j * 16 + r] = acc[half][b][i][j][e] * p.alpha;
         __syncthreads();
-        for (int it = 0; it < 128 * CPR / V3_NT; ++it) {
-            const int id = it * V3_NT + tid;
+        for (int it = 0; it < 128 * CPR / V4_NT; ++it) {
+            const int id = it * V4_NT + tid;
             const int row = id / CPR, cc = (id % CPR) * 8;
             const int gm = m0 + half * 128 + row, gn = n0 + cc;
             if (gm >= p.M || gn >= p.N) continue;
             float v[8];
-            const f32x4 v0 = *(const f32x4*)(cs + row * V3_CLD + cc), v1 = *(const f32x4*)(cs + row * V3_CLD + cc + 4);
+            const f32x4 v0 = *(const f32x4*)(cs + row * V4_CLD + cc), v1 = *(const f32x4*)(cs + row * V4_CLD + cc + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
             const bool full = gn + 8 <= p.N;
@@ -867,26 +952,44 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         if (akm) return launch_fast<128, false, true, false>(p, st, fl);
         return launch_fast<128, false, false, true>(p, st, fl);
     }
-    // 256 x 256 kernel: 0 (default) never, 1 for the wide short-K products (N >= 4096, K < 2048: the FFN-up forward and the FFN-down dX;
-    // 67 us against 72 us for the 128 x 128 kernel in isolation, but 0.1 ms SLOWER per training step - GELU / second-output epilogue in
-    // two halves, one workgroup per CU beside the side stream's kernels), 2 for every NT product (tests / diagnostics)
-    static const int v3_mode = [] { const char* e = getenv("AVAMD_GEMM_V3"); return e ? atoi(e) : 0; }();
-    if (!conv && !narrow && v3_mode > 0 && p.M >= 2048 && (v3_mode >= 2 ? p.N >= 256 : (p.N >= 4096 && p.K < 2048))) {
-        static bool v3_attr = false;
-        if (!v3_attr) {
-            if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS) != hipSuccess) {
-                av_set_error("av_gemm(fast v3): cannot raise dynamic LDS to %d", V3_LDS);
-                return AV_ERR_LAUNCH;
-            }
-            v3_attr = true;
-        }
-        const int nbM = av_cdiv(p.M, V3_BM), nbN = av_cdiv(p.N, V3_BN);
-        hipLaunchKernelGGL(gemm_nt_bf16_v3_kernel, dim3((unsigned)(nbM * (long long)nbN), 1, (unsigned)p.batch), dim3(V3_NT), V3_LDS, st, p, nbM, nbN, fl);
-        AV_LAUNCH_CHECK();
-        return AV_OK;
-    }
+    // Tiling choice for the plain NT products: estimated time = rounds x (K-tiles x time per K-tile + per-tile prologue / epilogue), from
+    // measurements on the step's shapes (tools/gemm_variants.py): 256 x 256 8-phase kernel 1.59 us per K-tile + 5 us on 256 slots,
+    // 256 x 128 three-stage kernel 0.85 + 2 on 256 slots, 128 x 128 kernel 1.0 + 2.5 on 512 slots (two workgroups per CU).
+    // AVAMD_GEMM_V4: 0 never, 1 (default) by that estimate, 2 whenever it applies (tests / diagnostics).
+    static const int v4_mode = [] { const char* e = getenv("AVAMD_GEMM_V4"); return e ? atoi(e) : 1; }();
     static const int v2_mode = [] { const char* e = getenv("AVAMD_GEMM_V2"); return e ? atoi(e) : 2; }();   // 0 never, 1 always, 2 (default) when K >= 2048
-    if (!conv && !narrow && p.M >= 512 && (v2_mode == 1 || (v2_mode == 2 && p.K >= 2048))) {
+    const bool v2_ok = !conv && !narrow && p.M >= 512 && (v2_mode == 1 || (v2_mode == 2 && p.K >= 2048));
+    if (!conv && !narrow && v4_mode > 0 && p.M >= 256 && p.N >= 256) {
+        const double nk = p.K / 64.0;
+        const long long t4 = (long long)av_cdiv(p.M, V4_BM) * av_cdiv(p.N, V4_BN) * p.batch;
+        const long long t2 = (long long)av_cdiv(p.M, V2_BM) * av_cdiv(p.N, V2_BN) * p.batch;
+        const long long t1 = (long long)av_cdiv(p.M, BM) * av_cdiv(p.N, 128) * p.batch;
+        const long long r4 = t4 % 256;
+        const double e4 = (t4 > 256 && r4 > 0 && r4 <= 128 && p.batch == 1) ? (double)(t4 / 256) * (nk * 1.59 + 5.0) + (double)((4 * r4 + 255) / 256) * (nk * 0.45 + 3.0)
+                                                                             : (double)((t4 + 255) / 256) * (nk * 1.59 + 5.0);
+        const double e2 = (double)((t2 + 255) / 256) * (nk * 0.85 + 2.0);
+        const double e1 = (double)((t1 + 511) / 512) * (nk * 1.0 + 2.5);
+        if (v4_mode >= 2 || e4 < (v2_ok ? (e2 < e1 ? e2 : e1) : e1)) {
+            static bool v4_attr = false;
+            if (!v4_attr) {
+                if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS) != hipSuccess) {
+                    av_set_error("av_gemm(fast v4): cannot raise dynamic LDS to %d", V4_LDS);
+                    return AV_ERR_LAUNCH;
+                }
+                v4_attr = true;
+            }
+            const int nbM = av_cdiv(p.M, V4_BM), nbN = av_cdiv(p.N, V4_BN);
+            const int ntile = nbM * nbN;
+            int nfull = ntile;
+            static const int v4_tail = [] { const char* e = getenv("AVAMD_GEMM_V4_TAIL"); return e ? atoi(e) : 1; }();
+            if (p.batch == 1 && v4_tail && ntile > 256 && ntile % 256 != 0 && ntile % 256 <= 128) nfull = ntile - ntile % 256;
+            const unsigned nblocks = (unsigned)(nfull + 4 * (ntile - nfull));
+            hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel, dim3(nblocks, 1, (unsigned)p.batch), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl, nfull);
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
+    }
+    if (v2_ok) {
         static bool v2_attr = false;
         if (!v2_attr) {
             if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS) != hipSuccess) {

@@ -236,7 +236,10 @@ def test_attention_fwd_bwd(dtype, B, H, Tq, Tk, D, masked):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (6368, 1024, 1024), (300, 4096, 1024), (1000, 3072, 1024), (257, 800, 1024),
-                                   (6368, 1024, 4096), (199, 512, 1536), (130, 200, 192)])
+                                   (6368, 1024, 4096), (199, 512, 1536), (130, 200, 192),
+                                   # 256 x 256 8-phase kernel: one round; a short last round cut into quadrant jobs (18 x 17 = 306 tiles, ragged M and
+                                   # N); a remainder too long for quadrant jobs (15 x 32 = 480 tiles); one K-tile; an odd number of K-tiles
+                                   (12736, 1024, 1024), (4400, 4328, 192), (3800, 8192, 128), (2048, 512, 64), (1500, 768, 320)])
 def test_fast_bf16_gemm(M, N, K):
     """LDS-DMA fast path (bf16, K-contiguous operands) against fp64, with every epilogue."""
     dtype = torch.bfloat16
