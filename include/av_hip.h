@@ -203,6 +203,13 @@ int av_l2norm_bwd(const float* y, const float* dy, const float* nrm, float* dx, 
 int av_lse_rows(const float* s, float* lse, float* rowsum, long long rows, int cols, int ld, void* stream);
 int av_contrastive_dsim(const float* s, const float* lse, void* out, int odt, long long rows, int cols, int ld, float coef,
                         void* stream);
+/* column-chunked forms (the N1 x N2 similarity matrix of contrastive.py:30-43 is never materialised whole: S is produced and
+ * consumed one [row chunk] x [column chunk] block at a time and recomputed in the backward): av_lse_rows_chunk merges the chunk's
+ * row LSE / row sum into the running values when accumulate != 0; av_contrastive_dsim_chunk uses the row LSE over ALL columns
+ * and 1 / total_cols */
+int av_lse_rows_chunk(const float* s, float* lse, float* rowsum, long long rows, int cols, int ld, int accumulate, void* stream);
+int av_contrastive_dsim_chunk(const float* s, const float* lse, void* out, int odt, long long rows, int cols, int ld, float coef,
+                              int total_cols, void* stream);
 int av_reduce_sum(const float* x, long long n, float* out, float scale, int accumulate, void* stream);
 /* loss combination of the trainer (model/trainer.py:111-119): out3 = {sum_i nll[i] w[i] + half_lambda (c1 + c2), 2 x first-half sum,
  * 2 x second-half sum}; nll, w fp32 [n] (n even: speaker 1 then speaker 2), c1 / c2 optional device scalars */
@@ -228,6 +235,14 @@ int av_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
  * weight); chunk c = elements [chunk_start[c], +chunk_elems) of tensor chunk_tensor[c]; all arrays live on the device */
 int av_adam_multi(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
                   int n_chunks, int chunk_elems, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* the same step under loss scaling (replaces torch.amp.GradScaler.step + .update, model/trainer.py:40,121-123 of the reference;
+ * torch/amp/grad_scaler.py:126-129 defaults): scaler_state = 5 device floats {scale, 1/scale, found_inf, growth tracker, steps taken}.
+ * Three launches, no host synchronisation: non-finite check over every gradient -> Adam with grad * grad_scale / scale, skipped when
+ * found_inf, bias corrections from the device-side step count -> scale update (x backoff on overflow, x growth after
+ * growth_interval clean steps) */
+int av_adam_multi_scaled(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
+                         int n_chunks, int chunk_elems, float beta1, float beta2, float eps, float grad_scale, float* scaler_state,
+                         float growth, float backoff, int growth_interval, void* stream);
 
 #ifdef __cplusplus
 }

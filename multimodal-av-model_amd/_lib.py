@@ -78,6 +78,8 @@ SIGNATURES = {
     "av_l2norm_fwd": [vp, vp, vp, ll, i32, f32, vp],
     "av_l2norm_bwd": [vp, vp, vp, vp, ll, i32, f32, vp],
     "av_lse_rows": [vp, vp, vp, ll, i32, i32, vp],
+    "av_lse_rows_chunk": [vp, vp, vp, ll, i32, i32, i32, vp],
+    "av_contrastive_dsim_chunk": [vp, vp, vp, i32, ll, i32, i32, f32, i32, vp],
     "av_contrastive_dsim": [vp, vp, vp, i32, ll, i32, i32, f32, vp],
     "av_reduce_sum": [vp, ll, vp, f32, i32, vp],
     "av_loss_combine": [vp, vp, vp, vp, f32, i32, vp, vp],
@@ -85,6 +87,7 @@ SIGNATURES = {
     "av_lip_gray_resize": [vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp],
     "av_mix_pair": [vp, ll, vp, ll, vp, vp, vp, vp, vp],
     "av_adam_multi": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, f32, vp],
+    "av_adam_multi_scaled": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, f32, f32, i32, vp],
     "av_adam_step": [vp, vp, vp, vp, ll, f32, f32, f32, f32, i32, f32, vp],
     "av_softmax_bwd_rows": [vp, i32, vp, vp, i32, ll, i32, f32, i32, vp],
 }

@@ -9,7 +9,11 @@ KEYS = ("epoch", "visual_encoder", "audio_encoder", "fusion", "decoder1", "optim
 
 
 def checkpoint_dict(epoch: int, trainer) -> dict:
-    return {
+    sc = getattr(trainer, "scaler", None)
+    if sc is not None and sc.enabled:
+        trainer.optimizer.sync_steps(sc)             # steps actually taken (overflowing steps are skipped on the device)
+    extra = {"scaler": sc.state_dict()} if sc is not None and sc.enabled else {}
+    return {**extra,
         "epoch": int(epoch),
         "visual_encoder": trainer.visual_encoder.state_dict(),
         "audio_encoder": trainer.audio_encoder.state_dict(),
@@ -38,4 +42,8 @@ def load_checkpoint(trainer, path: str, *, audio_encoder: bool = False, optimize
     trainer.decoder1.load_state_dict(ck["decoder1"])
     if optimizer:
         trainer.optimizer.load_state_dict(ck["optimizer"])
+        sc = getattr(trainer, "scaler", None)
+        if sc is not None and sc.enabled and "scaler" in ck:
+            sc.load_state_dict(ck["scaler"])
+            trainer.optimizer._scaler_seeded = None              # re-seed the device-side step count from the restored optimizer state
     return int(ck["epoch"]) + 1

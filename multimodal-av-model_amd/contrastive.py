@@ -9,6 +9,7 @@ CPU batch) to avoid the one host sync.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -22,19 +23,42 @@ WEIGHT_POS_ALIGN = 1.0
 WEIGHT_NEG_SUPPRESS = 0.3
 
 
+# The N1 x N2 similarity matrix is never held whole (~0.5 GB per term at configs[4]): S is produced one
+# [ROW_CHUNK x COL_CHUNK] block at a time into a reused workspace, reduced to the running row LSE / row sum, and RECOMPUTED block by
+# block in the backward (one extra K = 128 GEMM per block).  Workspace: ROW_CHUNK x COL_CHUNK x (4 + 2) B = 100 MB at the defaults.
+ROW_CHUNK = int(os.environ.get("AVAMD_CONTRAST_ROWS", "8192"))
+COL_CHUNK = int(os.environ.get("AVAMD_CONTRAST_COLS", "2048"))
+
+
+def _blocks(n_rows, n_cols):
+    for r0 in range(0, n_rows, ROW_CHUNK):
+        for c0 in range(0, n_cols, COL_CHUNK):
+            yield r0, min(ROW_CHUNK, n_rows - r0), c0, min(COL_CHUNK, n_cols - c0)
+
+
+def _sim_block(A_t, P_t, r0, nr, c0, nc, ws):
+    """S[r0:r0+nr, c0:c0+nc] = A P^T / tau into the fp32 workspace (leading dimension = nc rounded up to 64)."""
+    ld = (nc + 63) // 64 * 64
+    sim = ws[: nr * ld].view(nr, ld)
+    E = A_t.shape[1]
+    ops.gemm(A_t, P_t, sim, M=nr, N=nc, K=E, lda=E, ldb=E, ldc=ld, alpha=1.0 / TEMPERATURE, a_off=r0 * E, b_off=c0 * E)
+    return sim, ld
+
+
 def _term_fwd(A_t, P_t, n_rows, n_cols):
-    """returns (scalar [1] = mean_i lse_i - mean_ij s_ij, sim fp32 [n_rows, ld], lse, ld)"""
-    ld = (n_cols + 63) // 64 * 64          # padded columns are written as zeros by av_contrastive_dsim: K of the dA product = ld (fast GEMM)
+    """returns (scalar [1] = mean_i lse_i - mean_ij s_ij, lse [n_rows])"""
     dev = A_t.device
-    sim = torch.empty((n_rows, ld), dtype=torch.float32, device=dev)
-    ops.gemm(A_t, P_t, sim, M=n_rows, N=n_cols, K=A_t.shape[1], lda=A_t.shape[1], ldb=P_t.shape[1], ldc=ld, alpha=1.0 / TEMPERATURE)
     lse = torch.empty(n_rows, dtype=torch.float32, device=dev)
     rsum = torch.empty(n_rows, dtype=torch.float32, device=dev)
-    L.check(L.lib().av_lse_rows(ops.ptr(sim), ops.ptr(lse), ops.ptr(rsum), n_rows, n_cols, ld, ops.stream()), "av_lse_rows")
+    ws = torch.empty(min(ROW_CHUNK, n_rows) * ((min(COL_CHUNK, n_cols) + 63) // 64 * 64), dtype=torch.float32, device=dev)
+    for r0, nr, c0, nc in _blocks(n_rows, n_cols):
+        sim, ld = _sim_block(A_t, P_t, r0, nr, c0, nc, ws)
+        L.check(L.lib().av_lse_rows_chunk(ops.ptr(sim), ops.ptr(lse) + 4 * r0, ops.ptr(rsum) + 4 * r0, nr, nc, ld, int(c0 > 0), ops.stream()),
+                "av_lse_rows_chunk")
     val = torch.empty(1, dtype=torch.float32, device=dev)
     L.check(L.lib().av_reduce_sum(ops.ptr(lse), n_rows, ops.ptr(val), 1.0 / n_rows, 0, ops.stream()), "av_reduce_sum")
     L.check(L.lib().av_reduce_sum(ops.ptr(rsum), n_rows, ops.ptr(val), -1.0 / (n_rows * n_cols), 1, ops.stream()), "av_reduce_sum")
-    return val, sim, lse, ld
+    return val, lse
 
 
 _RANK = {}
@@ -72,13 +96,13 @@ class _ContrastFn(torch.autograd.Function):
         total = torch.zeros(1, dtype=torch.float32, device=dev)
         terms = []
         if n1 > 0 and n2 > 0:
-            val, sim, lse, ld = _term_fwd(f_t[:n1], f_t[n1:n1 + n2], n1, n2)
+            val, lse = _term_fwd(f_t[:n1], f_t[n1:n1 + n2], n1, n2)
             ops.axpby(WEIGHT_POS_ALIGN, val, 1.0, total)
-            terms.append((WEIGHT_POS_ALIGN, n1, n1 + n2, n2, sim, lse, ld))
+            terms.append((WEIGHT_POS_ALIGN, n1, n1 + n2, n2, lse))
         if n1 > 0 and n0 > 0:
-            val, sim, lse, ld = _term_fwd(f_t[:n1], f_t[n1 + n2:n], n1, n0)
+            val, lse = _term_fwd(f_t[:n1], f_t[n1 + n2:n], n1, n0)
             ops.axpby(WEIGHT_NEG_SUPPRESS, val, 1.0, total)
-            terms.append((WEIGHT_NEG_SUPPRESS, n1 + n2, n, n0, sim, lse, ld))
+            terms.append((WEIGHT_NEG_SUPPRESS, n1 + n2, n, n0, lse))
         fctx.s = dict(terms=terms, f=f, f_t=f_t, nrm=nrm, rows=rows, order=order, n=n, n1=n1, shape=(B, T, D), E=E, dtype=dtype)
         fctx.pw = pw
         return total.view(())
@@ -91,15 +115,20 @@ class _ContrastFn(torch.autograd.Function):
         dev = s["f"].device
         df = torch.zeros((n, E), dtype=torch.float32, device=dev)
         f_t = s["f_t"]
-        for (wgt, c0, c1, ncols, sim, lse, ld) in s["terms"]:
-            dsim = torch.empty((n1, ld), dtype=dtype, device=dev)
-            # d/dS of w*(mean lse - mean S) and the 1/temperature of S = A P^T / tau
-            L.check(L.lib().av_contrastive_dsim(ops.ptr(sim), ops.ptr(lse), ops.ptr(dsim), ops.dt(dsim), n1, ncols, ld,
-                                                wgt / (n1 * TEMPERATURE), ops.stream()), "av_contrastive_dsim")
-            Pm = f_t[c0:]                                                     # ld rows are read (rows >= ncols meet zero columns)
-            # dA += dS P ; dP = dS^T A
-            ops.gemm(dsim, Pm, df, M=n1, N=E, K=ld, lda=ld, ldb=E, ldc=E, b_mode=L.B_KN, R=df, ldr=E)
-            ops.matmul_tn(dsim[:, :ncols], f_t[:n1], out=df[c0:c1])          # dP = dS^T A  (transposes + fast GEMM)
+        for (wgt, k0, k1, ncols, lse) in s["terms"]:
+            A_t, P_t = f_t[:n1], f_t[k0:]                                     # P_t runs into the zero rows behind the last class
+            ws = torch.empty(min(ROW_CHUNK, n1) * ((min(COL_CHUNK, ncols) + 63) // 64 * 64), dtype=torch.float32, device=dev)
+            ds_ws = torch.empty(ws.numel(), dtype=dtype, device=dev)
+            for r0, nr, c0, nc in _blocks(n1, ncols):
+                sim, ld = _sim_block(A_t, P_t, r0, nr, c0, nc, ws)           # recomputed, not stored
+                dsim = ds_ws[: nr * ld].view(nr, ld)
+                # d/dS of w*(mean lse - mean S) and the 1/temperature of S = A P^T / tau; columns >= nc of the block are written as zeros
+                L.check(L.lib().av_contrastive_dsim_chunk(ops.ptr(sim), ops.ptr(lse) + 4 * r0, ops.ptr(dsim), ops.dt(dsim), nr, nc, ld,
+                                                          wgt / (n1 * TEMPERATURE), ncols, ops.stream()), "av_contrastive_dsim_chunk")
+                # dA[r0:r0+nr] += dS P_c  (ld >= nc rows of P are read: the surplus rows meet the zero columns of dS)
+                ops.gemm(dsim, P_t, df, M=nr, N=E, K=ld, lda=ld, ldb=E, ldc=E, b_mode=L.B_KN, R=df, ldr=E, b_off=c0 * E, c_off=r0 * E)
+                # dP_c (+)= dS^T A[r0:r0+nr]   (row chunks accumulate)
+                ops.matmul_tn(dsim[:, :nc], A_t[r0:r0 + nr], out=df[k0 + c0:k0 + c0 + nc], accumulate=r0 > 0)
         dproj = torch.empty_like(df)
         L.check(L.lib().av_l2norm_bwd(ops.ptr(s["f"]), ops.ptr(df), ops.ptr(s["nrm"]), ops.ptr(dproj), n, E, 1e-12, ops.stream()), "av_l2norm_bwd")
         dproj_t = ops.cast(dproj, dtype)

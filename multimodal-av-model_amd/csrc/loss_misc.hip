@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ s, float* __restrict__ lse, float* __restrict__ rsum,
-                                                       long long rows, int cols, int ld) {
+                                                       long long rows, int cols, int ld, int accumulate) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -50,16 +50,24 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
     for (int c = lane; c < cols; c += 64) e += expf(p[c] - mx);
     e = wave_sum(e);
     sm = wave_sum(sm);
-    if (lane == 0) { lse[row] = mx + logf(e); rsum[row] = sm; }
+    if (lane == 0) {
+        float l = mx + logf(e);
+        if (accumulate) {                                        // merge with the row's running values (earlier column chunks)
+            const float lo = lse[row], hi = fmaxf(lo, l);
+            l = hi + logf(expf(lo - hi) + expf(l - hi));
+            sm += rsum[row];
+        }
+        lse[row] = l; rsum[row] = sm;
+    }
 }
 
 // dsim = coef * (exp(sim - lse_row) - 1/cols)
 __global__ __launch_bounds__(256) void contrastive_dsim_kernel(const float* __restrict__ s, const float* __restrict__ lse, void* __restrict__ out,
-                                                               int odt, long long rows, int cols, int ld, float coef) {
+                                                               int odt, long long rows, int cols, int ld, float coef, float u) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float l = lse[row], u = 1.f / (float)cols;
+    const float l = lse[row];
     for (int c = lane; c < ld; c += 64) st_any(out, row * ld + c, odt, c < cols ? coef * (expf(s[row * ld + c] - l) - u) : 0.f);
 }
 
@@ -122,10 +130,66 @@ __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v,
     p -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
     return p;
 }
+// Loss-scaling state on the device (torch.amp.GradScaler semantics without the host synchronisation of its found_inf.item()):
+// gs[0] scale, gs[1] 1/scale, gs[2] found_inf (0/1), gs[3] growth tracker, gs[4] optimizer steps actually taken.
+enum { GS_SCALE = 0, GS_INV = 1, GS_INF = 2, GS_TRACK = 3, GS_STEP = 4 };
+
+// any non-finite gradient element -> gs[GS_INF] = 1   (torch/amp/grad_scaler.py:_unscale_grads_: _amp_foreach_non_finite_check_and_unscale_;
+// the unscale itself is folded into the Adam kernel)
+__global__ __launch_bounds__(256) void grad_check_multi_kernel(const unsigned long long* __restrict__ ptrs, const long long* __restrict__ sizes,
+                                                               const int* __restrict__ chunk_tensor, const long long* __restrict__ chunk_start,
+                                                               int chunk_elems, float* __restrict__ gs) {
+    const int c = blockIdx.x;
+    const int t = chunk_tensor[c];
+    const float* g = (const float*)ptrs[5 * t + 1];
+    const long long n = sizes[t];
+    const long long s0 = chunk_start[c];
+    long long s1 = s0 + chunk_elems;
+    if (s1 > n) s1 = n;
+    bool bad = false;
+    long long i = s0;
+    if (((uintptr_t)g % 16 == 0) && (s0 % 4 == 0)) {
+        const long long nv = (s1 - s0) / 4;
+        for (long long q = threadIdx.x; q < nv; q += 256) {
+            const f32x4 gg = *(const f32x4*)(g + s0 + 4 * q);
+            // x - x is 0 for finite x and NaN for +-inf / NaN
+            const float z = (gg[0] - gg[0]) + (gg[1] - gg[1]) + (gg[2] - gg[2]) + (gg[3] - gg[3]);
+            bad |= !(z == 0.f);
+        }
+        i = s0 + 4 * nv;
+    }
+    for (i += threadIdx.x; i < s1; i += 256) { const float x = g[i]; bad |= !((x - x) == 0.f); }
+    if (__any(bad) && (threadIdx.x & 63) == 0) gs[GS_INF] = 1.0f;          // every writer stores the same value
+}
+
+// torch/amp/grad_scaler.py:update (_amp_update_scale_): found_inf -> scale *= backoff, tracker = 0; otherwise tracker += 1 and
+// scale *= growth when it reaches the interval.  Also counts the optimizer steps that were not skipped and clears found_inf.
+__global__ void grad_scaler_update_kernel(float* __restrict__ gs, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (gs[GS_INF] != 0.f) {
+        gs[GS_SCALE] *= backoff;
+        gs[GS_TRACK] = 0.f;
+    } else {
+        gs[GS_STEP] += 1.f;
+        const float tr = gs[GS_TRACK] + 1.f;
+        if (tr >= (float)interval) { gs[GS_SCALE] *= growth; gs[GS_TRACK] = 0.f; }
+        else gs[GS_TRACK] = tr;
+    }
+    gs[GS_INV] = 1.0f / gs[GS_SCALE];
+    gs[GS_INF] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void adam_multi_kernel(const unsigned long long* __restrict__ ptrs, const long long* __restrict__ sizes,
                                                          const float* __restrict__ lrs, const int* __restrict__ chunk_tensor,
                                                          const long long* __restrict__ chunk_start, int chunk_elems, float b1, float b2,
-                                                         float eps, float bc1, float bc2_sqrt, float gscale) {
+                                                         float eps, float bc1, float bc2_sqrt, float gscale, const float* __restrict__ gs) {
+    if (gs) {                                                    // loss scaling: skip on overflow, unscale, step count from the device
+        if (gs[GS_INF] != 0.f) return;
+        gscale *= gs[GS_INV];
+        const float step = gs[GS_STEP] + 1.f;
+        bc1 = 1.f - powf(b1, step);
+        bc2_sqrt = sqrtf(1.f - powf(b2, step));
+    }
     const int c = blockIdx.x;
     const int t = chunk_tensor[c];
     float* p = (float*)ptrs[5 * t + 0];
@@ -190,14 +254,31 @@ extern "C" int av_l2norm_bwd(const float* y, const float* dy, const float* nrm, 
 extern "C" int av_lse_rows(const float* s, float* lse, float* rowsum, long long rows, int cols, int ld, void* stream) {
     AV_CHECK(s && lse && rowsum && cols > 0 && ld >= cols, "av_lse_rows: bad args");
     if (rows == 0) return AV_OK;
-    hipLaunchKernelGGL(lse_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, rowsum, rows, cols, ld);
+    hipLaunchKernelGGL(lse_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, rowsum, rows, cols, ld, 0);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_lse_rows_chunk(const float* s, float* lse, float* rowsum, long long rows, int cols, int ld, int accumulate, void* stream) {
+    AV_CHECK(s && lse && rowsum && cols > 0 && ld >= cols, "av_lse_rows_chunk: bad args");
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(lse_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, rowsum, rows, cols, ld, accumulate);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
 extern "C" int av_contrastive_dsim(const float* s, const float* lse, void* out, int odt, long long rows, int cols, int ld, float coef, void* stream) {
     AV_CHECK(s && lse && out && cols > 0 && ld >= cols, "av_contrastive_dsim: bad args");
     if (rows == 0) return AV_OK;
-    hipLaunchKernelGGL(contrastive_dsim_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, out, odt, rows, cols, ld, coef);
+    hipLaunchKernelGGL(contrastive_dsim_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, out, odt, rows, cols, ld, coef,
+                       1.f / (float)cols);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_contrastive_dsim_chunk(const float* s, const float* lse, void* out, int odt, long long rows, int cols, int ld, float coef,
+                                         int total_cols, void* stream) {
+    AV_CHECK(s && lse && out && cols > 0 && ld >= cols && total_cols >= cols, "av_contrastive_dsim_chunk: bad args");
+    if (rows == 0) return AV_OK;
+    hipLaunchKernelGGL(contrastive_dsim_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lse, out, odt, rows, cols, ld, coef,
+                       1.f / (float)total_cols);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -232,7 +313,24 @@ extern "C" int av_adam_multi(const void* ptrs, const long long* sizes, const flo
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)ptrs, sizes, lrs,
-                       chunk_tensor, chunk_start, chunk_elems, beta1, beta2, eps, bc1, bc2s, grad_scale);
+                       chunk_tensor, chunk_start, chunk_elems, beta1, beta2, eps, bc1, bc2s, grad_scale, (const float*)nullptr);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_adam_multi_scaled(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
+                                    int n_chunks, int chunk_elems, float beta1, float beta2, float eps, float grad_scale, float* scaler_state,
+                                    float growth, float backoff, int growth_interval, void* stream) {
+    AV_CHECK(ptrs && sizes && lrs && chunk_tensor && chunk_start && n_chunks >= 0 && chunk_elems > 0 && scaler_state && growth_interval >= 1,
+             "av_adam_multi_scaled: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_chunks > 0) {
+        hipLaunchKernelGGL(grad_check_multi_kernel, dim3(n_chunks), dim3(256), 0, st, (const unsigned long long*)ptrs, sizes, chunk_tensor, chunk_start,
+                           chunk_elems, scaler_state);
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, st, (const unsigned long long*)ptrs, sizes, lrs, chunk_tensor, chunk_start,
+                           chunk_elems, beta1, beta2, eps, 1.f, 1.f, grad_scale, (const float*)scaler_state);
+    }
+    hipLaunchKernelGGL(grad_scaler_update_kernel, dim3(1), dim3(64), 0, st, scaler_state, growth, backoff, growth_interval);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -23,7 +23,7 @@ from .. import ops
 from .. import _lib as L
 from ..beam_search import fast_decode, greedy_batch
 from ..contrastive import contrastive_loss_with_mask
-from ..optim import AvAdam
+from ..optim import AvAdam, AvGradScaler
 from ..parallel.dp import GradBucketReducer
 
 
@@ -72,7 +72,7 @@ class _CombineFn(torch.autograd.Function):
 class MultimodalTrainer:
     def __init__(self, visual_encoder, audio_encoder, fusion_module, decoder1, tokenizer, learning_rate=1e-4, device="cuda",
                  lambda_=0.1, audio_passes: Optional[int] = None, reducer: Optional[GradBucketReducer] = None, pair_batched: bool = True,
-                 visual_side_stream: bool = True):
+                 visual_side_stream: bool = True, loss_scaling: bool = False):
         self.visual_encoder = visual_encoder.to(device)
         self.audio_encoder = audio_encoder.to(device)
         self.fusion_module = fusion_module.to(device)
@@ -96,6 +96,9 @@ class MultimodalTrainer:
             {"params": list(self.fusion_module.parameters()), "lr": learning_rate},
             {"params": list(self.decoder1.parameters()), "lr": learning_rate},
         ])
+        # model/trainer.py:40 (GradScaler); off by default: bf16 operands need no loss scaling.  On = the reference's overflow-skip /
+        # growth / backoff law, evaluated on the device
+        self.scaler = AvGradScaler(device=device, enabled=loss_scaling)
         self.projection_layer = None
         self.fixed_projection = None        # (weight, bias) to inject instead of a fresh random layer (parity tests)
         self.reducer = reducer
@@ -282,7 +285,7 @@ class MultimodalTrainer:
         if self.reducer is not None:
             self._head_done = False
         out = self.forward_losses(batch)
-        out["total"].backward()
+        self.scaler.scale(out["total"]).backward()                 # model/trainer.py:121
         if self.reducer is not None:
             # wav2vec2 layer buckets were reduced inside its backward (overlapped), the decoder + fusion bucket at its start; if that
             # backward did not run (nothing trainable below the fusion) the bucket goes now
@@ -290,7 +293,8 @@ class MultimodalTrainer:
                 self._reduce_head()
             self.reducer.wait()
             self._head_done = False
-        self.optimizer.step()
+        self.scaler.step(self.optimizer)                           # model/trainer.py:122-123 (update() is part of the device-side step)
+        self.scaler.update()
         return out
 
     def _reduce_head(self):

@@ -11,6 +11,47 @@ from . import ops
 from .utils import shadow
 
 
+class AvGradScaler:
+    """torch.amp.GradScaler semantics (model/trainer.py:40,121-123 of the reference; torch/amp/grad_scaler.py:126-129 defaults: init
+    65536, growth 2x after 2000 clean steps, backoff 0.5x on overflow, overflowing steps skipped) kept ENTIRELY on the device: the
+    state is five floats {scale, 1/scale, found_inf, growth tracker, optimizer steps taken}; ``step`` is three launches (non-finite
+    check over every gradient, fused Adam that unscales / skips, scale update) and never synchronises with the host (torch's
+    ``scaler.step`` calls ``found_inf.item()``).  ``update()`` exists for call-sequence compatibility; the update has already
+    happened inside ``step``.  With bf16 MFMA operands (the package's perf mode) the scaling is not needed for range - bf16 has
+    fp32's exponent - but the reference's training loop is fp16 autocast + GradScaler, so its step-skipping law is reproduced."""
+
+    def __init__(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000,
+                 device="cuda", enabled: bool = True):
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.enabled = enabled
+        self.state = torch.tensor([init_scale, 1.0 / init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+
+    def scale(self, loss: torch.Tensor) -> torch.Tensor:
+        return loss * self.state[0] if self.enabled else loss
+
+    def step(self, optimizer: "AvAdam"):
+        return optimizer.step(scaler=self if self.enabled else None)
+
+    def update(self) -> None:            # folded into step(): the device already applied the growth / backoff law
+        return None
+
+    def get_scale(self) -> float:        # host synchronisation (diagnostics / checkpoints only)
+        return float(self.state[0])
+
+    def steps_taken(self) -> int:
+        return int(self.state[4])
+
+    def state_dict(self):
+        st = self.state.tolist()
+        return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(st[3])}
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+        self.state[0] = float(sd["scale"]); self.state[1] = 1.0 / float(sd["scale"]); self.state[3] = float(sd["_growth_tracker"])
+
+
 class AvAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -34,7 +75,15 @@ class AvAdam(torch.optim.Optimizer):
         return self._plan_data
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def sync_steps(self, scaler: "AvGradScaler") -> None:
+        """Under loss scaling the number of steps actually taken lives on the device (overflowing steps are skipped without telling
+        the host): copy it into the torch.optim.Adam-compatible ``state[p]['step']`` entries (one host sync; checkpoints)."""
+        n = scaler.steps_taken()
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = n
+
+    def step(self, closure=None, scaler: "AvGradScaler" = None):
         """One fused multi-tensor launch for all parameters that have a gradient (same step count, per-group lr)."""
         loss = closure() if closure is not None else None
         plist = []
@@ -57,6 +106,8 @@ class AvAdam(torch.optim.Optimizer):
         b1, b2 = self.param_groups[0]["betas"]
         eps = float(self.param_groups[0]["eps"])
         if len(steps) != 1 or any(g["betas"] != (b1, b2) or g["eps"] != eps for g in self.param_groups):
+            if scaler is not None:
+                raise NotImplementedError("AvAdam: loss scaling needs one step count / betas / eps for all parameters (the fused path)")
             return self._step_per_tensor(plist, loss)
         sizes, lrs, ct, cs, nch = self._plan(plist)
         grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p, _, _ in plist]
@@ -76,8 +127,16 @@ class AvAdam(torch.optim.Optimizer):
             self._ptr_dev.copy_(self._ptr_host, non_blocking=True)
             self._ptr_evt = torch.cuda.Event(); self._ptr_evt.record()
             self._ptr_list = flat
-        L.check(L.lib().av_adam_multi(ops.ptr(self._ptr_dev), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK, float(b1),
-                                      float(b2), eps, steps.pop(), float(self.grad_scale), ops.stream()), "av_adam_multi")
+        if scaler is not None:
+            if getattr(self, "_scaler_seeded", None) is not scaler:       # resume: the device-side step count starts from the optimizer's
+                scaler.state[4] = float(steps.pop() - 1)
+                self._scaler_seeded = scaler
+            L.check(L.lib().av_adam_multi_scaled(ops.ptr(self._ptr_dev), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK,
+                                                 float(b1), float(b2), eps, float(self.grad_scale), ops.ptr(scaler.state), scaler.growth_factor,
+                                                 scaler.backoff_factor, scaler.growth_interval, ops.stream()), "av_adam_multi_scaled")
+        else:
+            L.check(L.lib().av_adam_multi(ops.ptr(self._ptr_dev), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK, float(b1),
+                                          float(b2), eps, steps.pop(), float(self.grad_scale), ops.stream()), "av_adam_multi")
         self._keep = grads                                      # alive until the next step (stream-ordered use)
         params = [p for p, _, _ in plist]
         torch.autograd.graph.increment_version(params)          # other compute-dtype caches (re-layouts) rebuild

@@ -149,6 +149,68 @@ def test_contrastive_fwd_bwd(precision, tol, gtol, with_pad):
         assert rel < gtol
 
 
+@pytest.mark.parametrize("precision,tol,gtol", [("fp32", 1e-4, 2e-3), ("bf16", 5e-2, 0.1)])
+def test_contrastive_chunked_small_blocks(precision, tol, gtol, monkeypatch):
+    """Blocks of 24 rows x 64 columns force several row AND column chunks (running LSE merge, accumulated dP) on a small problem with
+    both terms present."""
+    _p(precision)
+    from oracle import av_oracle as O
+    init = pkg("utils.init"); con = pkg("contrastive")
+    monkeypatch.setattr(con, "ROW_CHUNK", 24); monkeypatch.setattr(con, "COL_CHUNK", 64)
+    B, T, D = 4, 80, 64
+    g = torch.Generator().manual_seed(9)
+    mid = torch.randn(B, T, D, generator=g)
+    m = torch.ones(B, T, dtype=torch.long); m[:, 25:] = 2; m[1:3, 10:] = 0; m[3, 70:] = 3
+    pw, pb = init.projection_params(D)
+    mr = mid.clone().requires_grad_(True)
+    ref = O.contrastive(mr, m.reshape(-1), pw, pb); ref.backward()
+    proj = torch.nn.Linear(D, 128).cuda()
+    with torch.no_grad():
+        proj.weight.copy_(pw); proj.bias.copy_(pb)
+    mc = mid.cuda().requires_grad_(True)
+    out = con.contrastive_loss_with_mask(mc, m.reshape(-1).cuda(), projection_layer=proj)
+    assert abs(float(out) - float(ref)) < tol * max(1.0, abs(float(ref))), (float(out), float(ref))
+    out.backward()
+    rel = float((mc.grad.cpu() - mr.grad).norm() / mr.grad.norm())
+    assert rel < gtol, rel
+
+
+def test_contrastive_streaming_at_config5_size():
+    """configs[4] (B = 128 / GPU x 4 s): 19 104 anchors x 6 368 positives (speaker 1) - the similarity matrix (0.49 GB in fp32) is
+    never allocated: peak extra memory of the loss stays near the 100 MB block workspace; value and gradient against the CPU oracle."""
+    _p("bf16")
+    from oracle import av_oracle as O
+    init = pkg("utils.init"); con = pkg("contrastive")
+    B, T, D = 128, 199, 1024
+    g = torch.Generator().manual_seed(10)
+    mid = torch.randn(B, T, D, generator=g) * 0.5
+    m = torch.ones(B, T, dtype=torch.long); m[:, 149:] = 2                      # mask1 of the synthetic clips: 0.75 overlap, then speaker alone
+    n1, n2 = int((m == 1).sum()), int((m == 2).sum())
+    assert (n1, n2) == (19072, 6400)
+    pw, pb = init.projection_params(D)
+    mr = mid.clone().requires_grad_(True)
+    ref = O.contrastive(mr, m.reshape(-1), pw, pb); ref.backward()
+    proj = torch.nn.Linear(D, 128).cuda()
+    with torch.no_grad():
+        proj.weight.copy_(pw); proj.bias.copy_(pb)
+    mc = mid.cuda().requires_grad_(True)
+    mflat = m.reshape(-1).cuda()
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = con.contrastive_loss_with_mask(mc, mflat, projection_layer=proj, counts=(n1, n2, 0))
+    out.backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    full_matrix = n1 * n2 * 4
+    print(f"config-5 contrastive: loss {float(out):.5f} (oracle {float(ref):.5f}); peak extra memory {peak / 1e6:.0f} MB; a full fp32 S would be {full_matrix / 1e6:.0f} MB")
+    assert abs(float(out) - float(ref)) < 5e-2 * max(1.0, abs(float(ref)))
+    rel = float((mc.grad.cpu() - mr.grad).norm() / mr.grad.norm())
+    assert rel < 0.1, rel
+    # O(N D) buffers of the loss itself (gathered rows 52 MB, three fp32 [N, D] gradient buffers 3 x 104 MB) + the 100 MB block workspace;
+    # the O(N1 N2) matrices (489 MB fp32 S + 244 MB bf16 dS) must not appear
+    assert peak < 600e6, peak
+
+
 def test_adam_step_matches_torch():
     L = pkg("_lib"); ops = pkg("ops")
     g = torch.Generator().manual_seed(9)
@@ -249,3 +311,68 @@ def test_avadam_writes_bf16_shadows_and_keeps_caches_coherent():
     ab = cache.get("ab", [a, b], torch.bfloat16, cat_ab, flat=True)
     torch.testing.assert_close(ab, torch.cat([a.data, b.data], 0).to(torch.bfloat16), rtol=0, atol=0)
     assert builds == ["ab", "c", "ab"]
+
+
+
+def test_grad_scaler_matches_torch_amp_on_injected_infs():
+    """AvGradScaler + fused Adam against torch.amp.GradScaler + torch.optim.Adam over 9 steps with overflowing gradients injected at
+    steps 2, 3 and 7 (growth interval 3): identical scale trajectory, skipped steps leave parameters, moments and the step count
+    untouched, clean steps agree with torch's unscaled Adam (model/trainer.py:40,121-123; torch/amp/grad_scaler.py)."""
+    optim = pkg("optim")
+    torch.manual_seed(3)
+    shapes = [(64, 33), (1000,), (7, 5, 3)]
+    p_ref = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    p_av = [p.detach().clone().requires_grad_(True) for p in p_ref]
+    o_ref = torch.optim.Adam([{"params": p_ref[:2], "lr": 1e-3}, {"params": p_ref[2:], "lr": 3e-4}])
+    o_av = optim.AvAdam([{"params": p_av[:2], "lr": 1e-3}, {"params": p_av[2:], "lr": 3e-4}])
+    s_ref = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    s_av = optim.AvGradScaler(init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    scales = []
+    for it in range(9):
+        gs = [torch.randn(s, device="cuda") for s in shapes]
+        sc_ref = float(s_ref.scale(torch.ones((), device="cuda")))           # also initialises torch's lazy scale tensor
+        sc_av = s_av.get_scale()
+        assert sc_ref == sc_av, (it, sc_ref, sc_av)
+        scales.append(sc_av)
+        for pr, pa, g in zip(p_ref, p_av, gs):
+            pr.grad = g * sc_ref; pa.grad = (g * sc_av).clone()
+        if it in (2, 7):
+            p_ref[1].grad[17] = float("inf"); p_av[1].grad[17] = float("inf")
+        if it == 3:
+            p_ref[2].grad[0, 0, 0] = float("nan"); p_av[2].grad[0, 0, 0] = float("nan")
+        before = [p.detach().clone() for p in p_av]
+        s_ref.step(o_ref); s_ref.update()
+        s_av.step(o_av); s_av.update()
+        for pr, pa, b in zip(p_ref, p_av, before):
+            if it in (2, 3, 7):
+                assert torch.equal(pa.detach(), b)                               # skipped
+            torch.testing.assert_close(pa.detach(), pr.detach(), rtol=2e-6, atol=2e-7)
+    assert scales == [1024.0, 1024.0, 1024.0, 512.0, 256.0, 256.0, 256.0, 512.0, 256.0]
+    assert s_av.steps_taken() == 6
+    o_av.sync_steps(s_av)
+    assert all(st["step"] == 6 for st in o_av.state.values())
+    assert all(int(st["step"]) == 6 for st in o_ref.state.values())
+    sd = s_av.state_dict()
+    assert sd["scale"] == s_ref.get_scale() and sd["_growth_tracker"] == s_ref.state_dict()["_growth_tracker"]
+
+
+def test_trainer_loss_scaling_step_equals_plain_step():
+    """A clean step with loss scaling on (scale 65536 folded out again inside the Adam kernel) moves the parameters like the plain step."""
+    from test_step_gpu import build
+    init = pkg("utils.init"); synth = pkg("dataset.synthetic"); tr = pkg("model.trainer")
+    cfg = init.W2V2_TINY
+    batch = synth.make_batch(2, 1.0, seed=5, ragged=True)
+    a = build(cfg, "fp32")
+    b0 = build(cfg, "fp32")
+    b = tr.MultimodalTrainer(b0.visual_encoder, b0.audio_encoder, b0.fusion_module, b0.decoder1, b0.tokenizer, learning_rate=1e-4, device="cuda",
+                             lambda_=0.1, loss_scaling=True)
+    b.fixed_projection = b0.fixed_projection
+    for _ in range(2):
+        oa, ob = a.train_step(batch), b.train_step(batch)
+        assert abs(float(oa["total"].detach()) - float(ob["total"].detach())) < 1e-5
+    assert b.scaler.get_scale() == 65536.0 and b.scaler.steps_taken() == 2
+    for ma, mb in ((a.audio_encoder, b.audio_encoder), (a.fusion_module, b.fusion_module), (a.decoder1, b.decoder1)):
+        sa, sb = ma.state_dict(), mb.state_dict()
+        for k in sa:
+            tol = 2e-4 if k.endswith("k_proj.bias") else 3e-6
+            assert float((sa[k].float() - sb[k].float()).abs().max()) < tol, k

@@ -16,15 +16,17 @@ for (B, H, T, D) in [(32, 16, 199, 64), (64, 16, 199, 64), (2, 16, 49, 64), (8, 
     dqkv = torch.empty_like(qkv)
     scale = D ** -0.5
 
-    def fwd():
-        return ops.attention_fwd(q, k, v, klen, scale)
+    def fwd(drop=None):
+        return ops.attention_fwd(q, k, v, klen, scale, drop=drop)
 
     o, lse = fwd()
 
-    def bwd():
-        ops.attention_bwd(q, k, v, do, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], klen, scale, o=o, lse=lse)
+    def bwd(drop=None):
+        ops.attention_bwd(q, k, v, do, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], klen, scale, o=o, lse=lse, drop=drop)
 
-    for name, fn, fl in (("fwd", fwd, 4.0 * B * H * T * T * D), ("bwd", bwd, 10.0 * B * H * T * T * D)):
+    dr = (0.1, 1234, 3)
+    for name, fn, fl in (("fwd", fwd, 4.0 * B * H * T * T * D), ("bwd", bwd, 10.0 * B * H * T * T * D),
+                         ("fwd+dropout", lambda: fwd(dr), 4.0 * B * H * T * T * D), ("bwd+dropout", lambda: bwd(dr), 10.0 * B * H * T * T * D)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -34,4 +36,4 @@ for (B, H, T, D) in [(32, 16, 199, 64), (64, 16, 199, 64), (2, 16, 49, 64), (8, 
             fn()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / 20
-        print(f"B={B} H={H} T={T} D={D} {name}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+        print(f"B={B} H={H} T={T} D={D} {name:12s}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
