@@ -109,6 +109,8 @@ int av_cast_dropout(const void* x, int xdt, void* y, int ydt, long long n, float
 /* debug / test: u[i] = the uniform number behind the mask of element i */
 int av_dropout_uniform(float* u, long long n, unsigned long long seed, unsigned int stream_id, void* stream);
 /* SpecAugment time masking (hf:1272-1296): x[row][:] = embed[:] where mask[row] != 0 */
+/* SpecAugment feature-axis masking (hf:1298-1316): x[b, t, c] = 0 for all t where mask[b * H + c] != 0 */
+int av_zero_feature_cols(void* x, int xdt, const unsigned char* mask, int B, int T, int H, void* stream);
 int av_overwrite_rows(void* x, int xdt, const unsigned char* mask, const float* embed, long long rows, int cols, void* stream);
 int av_axpby(float a, const void* x, int xdt, float b, float* y, long long n, void* stream); /* y = a*x + b*y */
 int av_mask_rows(void* x, int xdt, const unsigned char* keep, long long rows, int cols, void* stream); /* hf:752-755 */

@@ -437,6 +437,14 @@ __global__ void overwrite_rows_kernel(void* __restrict__ x, int xdt, const unsig
         if (mask[i / cols]) st_any(x, i, xdt, embed[i % cols]);
 }
 
+// SpecAugment along the feature axis (hf:1298-1316): x[b, t, c] = 0 for every t where mask[b, c] is set
+__global__ void zero_feature_cols_kernel(void* __restrict__ x, int xdt, const unsigned char* __restrict__ mask, long long n, int T, int H) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ((long long)T * H);
+        if (mask[b * H + (i % H)]) st_any(x, i, xdt, 0.f);
+    }
+}
+
 inline int ew_grid(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -612,6 +620,13 @@ extern "C" int av_dropout_uniform(float* u, long long n, unsigned long long seed
     AV_CHECK(u != nullptr, "av_dropout_uniform: null pointer");
     if (n == 0) return AV_OK;
     hipLaunchKernelGGL(dropout_uniform_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, u, n, seed, stream_id);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+extern "C" int av_zero_feature_cols(void* x, int xdt, const unsigned char* mask, int B, int T, int H, void* stream) {
+    AV_CHECK(x && mask && B > 0 && T > 0 && H > 0, "av_zero_feature_cols: bad args");
+    const long long n = (long long)B * T * H;
+    hipLaunchKernelGGL(zero_feature_cols_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, xdt, mask, n, T, H);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -76,7 +76,8 @@ def conv_out_lengths(cfg: dict, n):
 
 
 STOCHASTIC_DEFAULTS = dict(hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0,
-                           mask_time_prob=0.0, mask_time_length=10, mask_time_min_masks=2, mask_feature_prob=0.0)
+                           mask_time_prob=0.0, mask_time_length=10, mask_time_min_masks=2, mask_feature_prob=0.0, mask_feature_length=10,
+                           mask_feature_min_masks=0)
 # dropout streams: layer*8 + site; sites 0 attention-out, 1 FFN activation, 2 FFN out, 3 attention probabilities
 S_FEATPROJ, S_POS = 0xF0000001, 0xF0000002
 
@@ -227,8 +228,6 @@ class Wav2Vec2ModelHIP(nn.Module):
         # train-mode stochastic regularisers of wav2vec2 (hf:701,774,1272-1316); all probabilities default to 0
         sc = {k: cfg.get(k, v) for k, v in STOCHASTIC_DEFAULTS.items()}
         tm = self.training
-        if tm and sc["mask_feature_prob"] > 0:
-            raise NotImplementedError("SpecAugment feature-axis masking (mask_feature_prob) is not built; set it to 0")
         hd_p = sc["hidden_dropout"] if tm else 0.0
         at_p = sc["attention_dropout"] if tm else 0.0
         ac_p = sc["activation_dropout"] if tm else 0.0
@@ -264,6 +263,10 @@ class Wav2Vec2ModelHIP(nn.Module):
             smt = torch.from_numpy(sm.astype("uint8")).to(dev)
             L.check(L.lib().av_overwrite_rows(ops.ptr(h), ops.dt(h), ops.ptr(smt), ops.ptr(self.P("masked_spec_embed").data), B * T, Hd,
                                               ops.stream()), "av_overwrite_rows")
+        if tm and sc["mask_feature_prob"] > 0 and cfg.get("apply_spec_augment", True):   # hf:1298-1316: drawn AFTER the time mask, same numpy RNG
+            fmask = specaugment_mask(B, Hd, sc["mask_feature_prob"], sc["mask_feature_length"], [Hd] * B, sc["mask_feature_min_masks"])
+            fmt = torch.from_numpy(fmask.astype("uint8")).to(dev)
+            L.check(L.lib().av_zero_feature_cols(ops.ptr(h), ops.dt(h), ops.ptr(fmt), B, T, Hd, ops.stream()), "av_zero_feature_cols")
         if keep is not None:
             ops.mask_rows_(h, keep)                                                      # hf:752-755
         # positional conv (grouped, k taps) as an implicit-im2col GEMM per group, + bias, GELU, + residual
@@ -466,7 +469,8 @@ def load_local_config(path: str) -> dict:
             "num_conv_pos_embeddings", "num_conv_pos_embedding_groups", "layer_norm_eps")
     out = {k: (tuple(c[k]) if isinstance(c[k], list) else c[k]) for k in keys}
     hf_defaults = dict(hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, feat_proj_dropout=0.0, layerdrop=0.1,
-                       mask_time_prob=0.05, mask_time_length=10, mask_time_min_masks=2, mask_feature_prob=0.0, apply_spec_augment=True)
+                       mask_time_prob=0.05, mask_time_length=10, mask_time_min_masks=2, mask_feature_prob=0.0, mask_feature_length=10,
+                       mask_feature_min_masks=0, apply_spec_augment=True)
     for k, v in hf_defaults.items():          # a real checkpoint trains with its own regularisation settings
         out[k] = c.get(k, v)
     out["conv_bias"] = bool(c.get("conv_bias", False))       # HF default False; XLSR-53 checkpoints have True

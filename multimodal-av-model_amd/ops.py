@@ -395,8 +395,6 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: T
     B, Tq, H, D = q.shape
     Tk = k.shape[1]
     dp, dseed, dstream = (float(drop[0]), int(drop[1]), int(drop[2])) if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
-    if dp > 0 and not (q.dtype == torch.bfloat16 and o is not None and lse is not None):
-        raise NotImplementedError("attention-probability dropout is implemented in the fused bf16 backward only")
     if q.dtype == torch.bfloat16 and o is not None and lse is not None:     # fused flash-style backward (attention_bwd.hip)
         _chk_view(o, "o")
         st = (C.c_longlong * 16)(*[x for t in (q, k, v, o, do, dq, dk, dv) for x in (t.stride(0), t.stride(1))])
@@ -406,20 +404,26 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: T
                 lambda: L.check(L.lib().av_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                                          B, H, Tq, Tk, D, st, ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_bwd"))
         return
-    ld = (Tk + 7) // 8 * 8
+    # unfused form (fp32 parity mode).  With dropout the row pitch equals the Philox row pitch of the attention kernels (keys padded
+    # to 4, attn_common.h), so the mask of element (b, h, q, k) is the mask of linear index row * ld + k of these buffers
+    ld = (Tk + 3) // 4 * 4 if dp > 0 else (Tk + 7) // 8 * 8
     dev = q.device
+    drop_t = (dp, dseed, dstream)
     S = torch.empty((B, H, Tq, ld), dtype=torch.float32, device=dev)
     bh = dict(batch=B * H, batch_inner=H)
     gemm(q, k, S, M=Tq, N=Tk, K=D, lda=q.stride(1), ldb=k.stride(1), ldc=ld, sA=D, oA=q.stride(0), sB=D, oB=k.stride(0),
          sC=Tq * ld, oC=H * Tq * ld, **bh)
     P = torch.empty((B, H, Tq, ld), dtype=q.dtype, device=dev)
     L.check(L.lib().av_softmax_rows(ptr(S), ptr(P), dt(P), B * H * Tq, Tk, scale, ptr(klen), H * Tq, ld, stream()), "av_softmax_rows")
-    # dV[key, d] = sum_q P[q, key] dO[q, d]
-    gemm(P, do, dv, M=Tk, N=D, K=Tq, lda=ld, ldb=do.stride(1), ldc=dv.stride(1), a_mode=L.A_TRANS, b_mode=L.B_KN,
+    # dV[key, d] = sum_q Pd[q, key] dO[q, d]   (Pd = P o mask / (1 - p): what the forward multiplied V with, hf:457)
+    Pd = cast_dropout(P, P.dtype, drop_t) if dp > 0 else P
+    gemm(Pd, do, dv, M=Tk, N=D, K=Tq, lda=ld, ldb=do.stride(1), ldc=dv.stride(1), a_mode=L.A_TRANS, b_mode=L.B_KN,
          sA=Tq * ld, oA=H * Tq * ld, sB=D, oB=do.stride(0), sC=D, oC=dv.stride(0), **bh)
     # dP = dO V^T  (into S)
     gemm(do, v, S, M=Tq, N=Tk, K=D, lda=do.stride(1), ldb=v.stride(1), ldc=ld, sA=D, oA=do.stride(0), sB=D, oB=v.stride(0),
          sC=Tq * ld, oC=H * Tq * ld, **bh)
+    if dp > 0:
+        S = cast_dropout(S, torch.float32, drop_t)           # dP = dPd o mask / (1 - p)
     dS = torch.empty((B, H, Tq, ld), dtype=q.dtype, device=dev)
     L.check(L.lib().av_softmax_bwd_rows(ptr(P), dt(P), ptr(S), ptr(dS), dt(dS), B * H * Tq, Tk, scale, ld, stream()), "av_softmax_bwd_rows")
     # dQ = dS K ; dK = dS^T Q

@@ -49,10 +49,10 @@ def test_gemm_epilogue_dropout_matches_mask(dtype):
     torch.testing.assert_close(out, ref, **tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])                              # fp32: tiled forward + unfused backward
 @pytest.mark.parametrize("B,H,T,D", [(2, 4, 70, 64), (1, 2, 130, 128), (1, 2, 300, 64)])      # 300: the chunked T > 256 kernels with dropout
-def test_attention_dropout_fwd_bwd_same_mask(B, H, T, D):
+def test_attention_dropout_fwd_bwd_same_mask(B, H, T, D, dtype):
     ops = pkg("ops")
-    dtype = torch.bfloat16
     p_, seed, stream = 0.15, 4242, 11
     qkv = torch.randn(B, T, 3, H, D, device="cuda").to(dtype)
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
@@ -64,14 +64,16 @@ def test_attention_dropout_fwd_bwd_same_mask(B, H, T, D):
     qr, kr, vr = (t.float().permute(0, 2, 1, 3).detach().clone().requires_grad_(True) for t in (q, k, v))
     P = torch.softmax((qr.double() @ kr.double().transpose(2, 3)) * scale, -1)
     ref = ((P * m) @ vr.double()).float()
-    torch.testing.assert_close(o.float().permute(0, 2, 1, 3), ref, rtol=3e-2, atol=3e-2)
+    ft = 3e-2 if dtype == torch.bfloat16 else 1e-3
+    torch.testing.assert_close(o.float().permute(0, 2, 1, 3), ref, rtol=ft, atol=ft)
     torch.testing.assert_close(lse, torch.logsumexp((qr.double() @ kr.double().transpose(2, 3)) * scale, -1).float(), rtol=2e-2, atol=5e-2)
     do = torch.randn(B, T, H, D, device="cuda").to(dtype)
     ref.backward(do.float().permute(0, 2, 1, 3))
     dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
     ops.attention_bwd(q, k, v, do, dq, dk, dv, None, scale, o=o, lse=lse, drop=(p_, seed, stream))
+    tol = 6e-2 if dtype == torch.bfloat16 else 2e-3
     for a, g in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad)):
-        torch.testing.assert_close(a.float().permute(0, 2, 1, 3), g, rtol=6e-2, atol=6e-2)
+        torch.testing.assert_close(a.float().permute(0, 2, 1, 3), g, rtol=tol, atol=tol)
 
 
 def _audio(cfg_extra, precision):
@@ -152,3 +154,47 @@ def test_specaugment_mask_matches_hf_function():
             am[i, :l] = 1
         np.random.seed(seed); ref = tm._compute_mask_indices((B, T), prob, ln, attention_mask=am, min_masks=mn)
         assert (mine == ref).all()
+
+
+
+def test_specaugment_time_and_feature_masks_vs_hf_model():
+    """SpecAugment end to end (time axis hf:1272-1296 + feature axis hf:1298-1316) against the installed HF Wav2Vec2Model in train
+    mode with every dropout at 0: same numpy seed => same masks (drawn in HF's order: time first, then features) => same
+    last_hidden_state and hidden_states[6:10] mean within the fp32 gate."""
+    tf = pytest.importorskip("transformers")
+    init = pkg("utils.init"); enc = pkg("model.encoder")
+    pkg("precision").set_precision("fp32")
+    cfg = dict(init.W2V2_TINY, mask_time_prob=0.3, mask_time_length=4, mask_time_min_masks=2, mask_feature_prob=0.25, mask_feature_length=5,
+               mask_feature_min_masks=1)
+    hc = tf.Wav2Vec2Config(hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                           intermediate_size=cfg["intermediate_size"], conv_dim=tuple(cfg["conv_dim"]), conv_kernel=tuple(cfg["conv_kernel"]),
+                           conv_stride=tuple(cfg["conv_stride"]), num_conv_pos_embeddings=cfg["num_conv_pos_embeddings"],
+                           num_conv_pos_embedding_groups=cfg["num_conv_pos_embedding_groups"], feat_extract_norm="layer", do_stable_layer_norm=True,
+                           conv_bias=True, hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0, final_dropout=0.0,
+                           layerdrop=0.0, mask_time_prob=0.3, mask_time_length=4, mask_time_min_masks=2, mask_feature_prob=0.25,
+                           mask_feature_length=5, mask_feature_min_masks=1, attn_implementation="eager")
+    hf = tf.Wav2Vec2Model(hc)
+    sd = init.w2v2_state_dict(cfg, seed=4, prefix="")
+    hf.load_state_dict(sd)
+    hf.train()
+    ae = enc.AudioEncoder(dict(cfg), freeze=True).cuda()
+    ae.model.load_state_dict(sd)
+    ae.train()
+    g = torch.Generator().manual_seed(2)
+    wav = torch.randn(3, 16000, generator=g) * 0.3
+    am = torch.ones(3, 16000, dtype=torch.long); am[1, 12000:] = 0
+    np.random.seed(11)
+    with torch.no_grad():
+        ref = hf(wav, attention_mask=am, output_hidden_states=True)
+    ref_last = ref.last_hidden_state
+    ref_mid = torch.stack(ref.hidden_states[6:10], 0).mean(0)
+    np.random.seed(11)
+    with torch.no_grad():
+        last, mid = ae(wav.cuda(), attention_mask=am.bool().cuda())
+    assert float((last.cpu() - ref_last).abs().max()) < 1e-3
+    assert float((mid.cpu() - ref_mid).abs().max()) < 1e-3
+    # the masks did something: an unmasked run differs
+    ae.model.cfg.update(mask_time_prob=0.0, mask_feature_prob=0.0)
+    with torch.no_grad():
+        last0, _ = ae(wav.cuda(), attention_mask=am.bool().cuda())
+    assert float((last0 - last).abs().max()) > 1e-2
