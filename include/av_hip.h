@@ -109,6 +109,13 @@ int av_cast_dropout(const void* x, int xdt, void* y, int ydt, long long n, float
 /* debug / test: u[i] = the uniform number behind the mask of element i */
 int av_dropout_uniform(float* u, long long n, unsigned long long seed, unsigned int stream_id, void* stream);
 /* SpecAugment time masking (hf:1272-1296): x[row][:] = embed[:] where mask[row] != 0 */
+/* fused cross-attention block of CrossAttentionFusion (model/fusion_module.py:57-61; nn.MultiheadAttention need-weights path,
+ * torch:functional.py:6206,6576-6606): packed in-projection + attention core of one (batch item, head) per workgroup.
+ * a, v [B, T, 512] bf16 (audio / visual projections); w_in [1536, 512] bf16, b_in [1536] fp32 (in_proj_weight / in_proj_bias);
+ * o [B, T, 512] bf16 = concat_h softmax(scale q_h k_h^T) v_h; q_out [B, T, 512], kv_out [B, T, 2, 512], lse [B, H, T] are optional
+ * (what the backward reads).  embed_dim 512, 4 heads x 128, T <= 112 */
+int av_fusion_xattn_fwd(const void* a, const void* v, const void* w_in, const float* b_in, void* q_out, void* kv_out, void* o,
+                        float* lse, int B, int T, int E, int H, float scale, void* stream);
 /* SpecAugment feature-axis masking (hf:1298-1316): x[b, t, c] = 0 for all t where mask[b * H + c] != 0 */
 int av_zero_feature_cols(void* x, int xdt, const unsigned char* mask, int B, int T, int H, void* stream);
 int av_overwrite_rows(void* x, int xdt, const unsigned char* mask, const float* embed, long long rows, int cols, void* stream);

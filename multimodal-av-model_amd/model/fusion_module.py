@@ -22,6 +22,8 @@ Tensor = torch.Tensor
 # one persistent launch per BiLSTM layer (bf16, H = 512) instead of one launch per time step; AVAMD_LSTM_PERSISTENT=0 disables
 import os as _os
 PERSISTENT_LSTM = _os.environ.get("AVAMD_LSTM_PERSISTENT", "1") != "0"
+# in-projection + attention core of the cross-attention in one kernel (bf16, embed 512 = 4 x 128, T_v <= 112); 0 = separate GEMMs + attention
+FUSED_XATTN = _os.environ.get("AVAMD_FUSED_XATTN", "1") != "0"
 
 
 def lstm_forward(mod: "CrossAttentionFusion", x_tm: Tensor, save: bool):
@@ -141,10 +143,13 @@ class _FusionFn(torch.autograd.Function):
         mha = mod.cross_attn_audio
         Win = c(mha.in_proj_weight)
         bin_ = mha.in_proj_bias.data
-        q = ops.linear(a, Win[:E], bin_[:E].contiguous()).view(B, Tv, nh, hd)
-        kv = ops.linear(v, Win[E:], bin_[E:].contiguous()).view(B, Tv, 2, nh, hd)
         scale = hd ** -0.5                                   # torch scales q by 1/sqrt(hd) (torch:functional.py:6578)
-        o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], None, scale, need_lse=save)
+        if FUSED_XATTN and dtype == torch.bfloat16 and E == 512 and nh == 4 and Tv <= 112:
+            o, q, kv, lse = ops.fusion_xattn_fwd(a, v, Win, bin_, nh, scale, save)
+        else:
+            q = ops.linear(a, Win[:E], bin_[:E].contiguous()).view(B, Tv, nh, hd)
+            kv = ops.linear(v, Win[E:], bin_[E:].contiguous()).view(B, Tv, 2, nh, hd)
+            o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], None, scale, need_lse=save)
         a2v = ops.linear(o.view(B, Tv, E), c(mha.out_proj.weight), mha.out_proj.bias.data)
         fused = ops.linear(a2v, c(mod.fusion_proj.weight), mod.fusion_proj.bias.data)
         x_tm = torch.empty((Tv, B, E), dtype=dtype, device=dev)

@@ -385,6 +385,24 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, klen: Optional[Tensor], scale
     return o, lse
 
 
+def fusion_xattn_fwd(a: Tensor, v: Tensor, w_in: Tensor, b_in: Tensor, nh: int, scale: float, save: bool):
+    """Fused in-projection + cross-attention core (csrc/fusion_attn.hip): a, v [B, T, E] bf16 -> (o [B,T,nh,hd], q [B,T,nh,hd] | None,
+    kv [B,T,2,nh,hd] | None, lse [B,nh,T] | None)."""
+    B, T, E = a.shape
+    hd = E // nh
+    assert a.is_contiguous() and v.is_contiguous() and w_in.is_contiguous() and w_in.shape == (3 * E, E) and b_in.dtype == torch.float32
+    o = torch.empty((B, T, nh, hd), dtype=a.dtype, device=a.device)
+    q = torch.empty((B, T, nh, hd), dtype=a.dtype, device=a.device) if save else None
+    kv = torch.empty((B, T, 2, nh, hd), dtype=a.dtype, device=a.device) if save else None
+    lse = torch.empty((B, nh, T), dtype=torch.float32, device=a.device) if save else None
+    fl = B * (6.0 * T * E * E + 4.0 * T * T * E)
+    by = a.element_size() * (2 * B * T * E + 3 * E * E + B * T * E * (4 if save else 1))
+    _probed("blockfwd", fl, by,
+            lambda: L.check(L.lib().av_fusion_xattn_fwd(ptr(a), ptr(v), ptr(w_in), ptr(b_in), ptr(q), ptr(kv), ptr(o), ptr(lse), B, T, E, nh, scale,
+                                                        stream()), "av_fusion_xattn_fwd"))
+    return o, q, kv, lse
+
+
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: Tensor, dv: Tensor, klen: Optional[Tensor],
                   scale: float, o: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop: Optional[tuple] = None) -> None:
     """Backward of attention_fwd from batched MFMA GEMMs + row kernels (P is re-materialised, T x T is small here):

@@ -438,3 +438,30 @@ def test_device_input_pipeline_equals_numpy_restatement():
     assert batch["audio"].is_cuda and batch["audio"].shape == (2, 4000) and batch["lip1"].shape == (2, 6, 1, 96, 96)
     assert batch["mask1"][1, 2500:].eq(3).all() and batch["mask1"][0, 3000:].eq(2).all() and batch["mask2"][0, 3000:].eq(0).all()
     assert batch["lip2_lengths"].tolist() == [5, 4] and batch["text1"].tolist() == [[5, 6, 7], [5, 6, 7]]
+
+
+
+@pytest.mark.parametrize("B,T", [(3, 100), (2, 25), (1, 112), (5, 7), (130, 100)])
+def test_fused_cross_attention_block(B, T):
+    """csrc/fusion_attn.hip (packed in-projection + attention core per (item, head)) against the fp64 statement of
+    nn.MultiheadAttention's need-weights path (torch:functional.py:6576-6606: q scaled by 1/sqrt(128), softmax, no masks)."""
+    E, nh, hd = 512, 4, 128
+    dt_ = torch.bfloat16
+    a = _rand(B, T, E, dtype=dt_); v = _rand(B, T, E, dtype=dt_)
+    w = _rand(3 * E, E, dtype=dt_, scale=1 / math.sqrt(E)); bias = _rand(3 * E, scale=0.1)
+    o, q, kv, lse = ops.fusion_xattn_fwd(a, v, w, bias, nh, hd ** -0.5, True)
+    wd, bd = w.double(), bias.double()
+    qr = (a.double() @ wd[:E].t() + bd[:E]).view(B, T, nh, hd)
+    kr = (v.double() @ wd[E:2 * E].t() + bd[E:2 * E]).view(B, T, nh, hd)
+    vr = (v.double() @ wd[2 * E:].t() + bd[2 * E:]).view(B, T, nh, hd)
+    torch.testing.assert_close(q.double(), qr, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(kv[:, :, 0].double(), kr, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(kv[:, :, 1].double(), vr, rtol=2e-2, atol=2e-2)
+    # the attention core consumes the bf16-rounded projections (as the unfused path does)
+    qb, kb, vb = q.double().permute(0, 2, 1, 3), kv[:, :, 0].double().permute(0, 2, 1, 3), kv[:, :, 1].double().permute(0, 2, 1, 3)
+    s = (qb @ kb.transpose(2, 3)) * hd ** -0.5
+    ref = (torch.softmax(s, -1) @ vb).permute(0, 2, 1, 3)
+    torch.testing.assert_close(o.double(), ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse.double(), torch.logsumexp(s, -1), rtol=1e-3, atol=2e-3)
+    o2, q2, kv2, lse2 = ops.fusion_xattn_fwd(a, v, w, bias, nh, hd ** -0.5, False)
+    assert q2 is None and kv2 is None and lse2 is None and torch.equal(o2, o)
