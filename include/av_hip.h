@@ -95,6 +95,12 @@ int av_layernorm_fwd(const void* x, int xdt, const float* gamma, const float* be
 int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk,
                      long long rows, int cols, void* dx_bf16, void* stream);
+/* the same with dropout folded into the bf16 copy: dx_bf16 = bf16(dx o mask / (1 - p)), mask = Philox(seed, stream, element index):
+ * the backward of a dropout that sits between this LayerNorm's input and the next dX GEMM (hf:633,648: hidden dropout) */
+int av_layernorm_bwd_drop(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
+                          const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk,
+                          long long rows, int cols, void* dx_bf16, float drop_p, unsigned long long drop_seed,
+                          unsigned int drop_stream, void* stream);
 /* F.log_softmax(dim=-1) (model/decoder.py:25) and its backward: dx = dy - exp(y) * sum(dy) */
 int av_log_softmax_fwd(const void* x, int xdt, float* y, long long rows, int cols, void* stream);
 int av_log_softmax_bwd(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, void* stream);

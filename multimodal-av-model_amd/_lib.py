@@ -44,6 +44,7 @@ SIGNATURES = {
     "av_transpose": [vp, i32, vp, i32, i32, i32, ll, i32, vp],
     "av_sum_slices": [vp, i32, ll, ll, f32, vp, i32, vp],
     "av_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, ll, i32, f32, i32, vp],
+    "av_layernorm_bwd_drop": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp, f32, C.c_ulonglong, C.c_uint, vp],
     "av_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp, vp],
     "av_log_softmax_fwd": [vp, i32, vp, ll, i32, vp],
     "av_log_softmax_bwd": [vp, vp, vp, i32, ll, i32, vp],

@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ dres,
                                                          float* __restrict__ dx, float* __restrict__ dgb, long long rows,
-                                                         long long rows_per_block, bf16_t* __restrict__ dxl) {
+                                                         long long rows_per_block, bf16_t* __restrict__ dxl, float drop_p,
+                                                         unsigned long long drop_seed, unsigned drop_stream) {
     constexpr int cols = NV * 256;
+    const float drop_ik = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     __shared__ float red[4][2][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
@@ -217,10 +219,17 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
                 for (int e = 0; e < 4; ++e) o[e] += rr[e];
             }
             *(f32x4*)(dx + off) = o;
-            if (dxl) {                                       // bf16 copy for the GEMM that consumes dx next (saves a cast pass)
-                bf16x4 ol;
+            if (dxl) {                                       // bf16 copy for the GEMM that consumes dx next (saves a cast pass); with
+                bf16x4 ol;                                   // drop_p > 0 the copy is dx o mask / (1 - p): the dropout backward of that GEMM's input
+                if (drop_p > 0.f) {
+                    float m4[4];
+                    drop_mult4(drop_seed, drop_stream, (unsigned long long)off, drop_p, drop_ik, m4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ol[e] = (bf16_t)o[e];
+                    for (int e = 0; e < 4; ++e) ol[e] = (bf16_t)(o[e] * m4[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ol[e] = (bf16_t)o[e];
+                }
                 *(bf16x4*)(dxl + off) = ol;
             }
         }
@@ -481,10 +490,19 @@ extern "C" int av_layernorm_fwd(const void* x, int xdt, const float* gamma, cons
     return AV_OK;
 }
 
+extern "C" int av_layernorm_bwd_drop(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
+                                     const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk, long long rows,
+                                     int cols, void* dx_bf16, float drop_p, unsigned long long drop_seed, unsigned int drop_stream, void* stream);
 extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
                                 const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk, long long rows,
                                 int cols, void* dx_bf16, void* stream) {
+    return av_layernorm_bwd_drop(x, xdt, dy, dydt, gamma, mean, rstd, dres, dx, dgb_partial, nblk, rows, cols, dx_bf16, 0.f, 0ull, 0u, stream);
+}
+extern "C" int av_layernorm_bwd_drop(const void* x, int xdt, const void* dy, int dydt, const float* gamma, const float* mean,
+                                     const float* rstd, const float* dres, float* dx, float* dgb_partial, int nblk, long long rows,
+                                     int cols, void* dx_bf16, float drop_p, unsigned long long drop_seed, unsigned int drop_stream, void* stream) {
     AV_CHECK(x && dy && gamma && mean && rstd && dx, "av_layernorm_bwd: null pointer");
+    AV_CHECK(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || dx_bf16), "av_layernorm_bwd: drop_p=%f needs dx_bf16 and [0,1)", drop_p);
     AV_CHECK(!dx_bf16 || (uintptr_t)dx_bf16 % 8 == 0, "av_layernorm_bwd: dx_bf16 must be 8-byte aligned");
     AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_layernorm_bwd: cols=%d out of range", cols);
     AV_CHECK(nblk >= 1, "av_layernorm_bwd: nblk=%d", nblk);
@@ -496,7 +514,7 @@ extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt
         const bool da = dydt == AV_F32 ? ((uintptr_t)dy % 16 == 0) : ((uintptr_t)dy % 8 == 0);
         if ((cols == 256 || cols == 512 || cols == 1024 || cols == 2048) && xa && da && (uintptr_t)gamma % 16 == 0 && (uintptr_t)dx % 16 == 0 &&
             (!dres || (uintptr_t)dres % 16 == 0)) {
-#define LBV(N, P) hipLaunchKernelGGL((ln_bwd_vec_kernel<N, P>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx, dgb_partial, rows, rpb, (bf16_t*)dx_bf16)
+#define LBV(N, P) hipLaunchKernelGGL((ln_bwd_vec_kernel<N, P>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, xdt, dy, dydt, gamma, mean, rstd, dres, dx, dgb_partial, rows, rpb, (bf16_t*)dx_bf16, drop_p, drop_seed, drop_stream)
 #define LBV_N(P) do { if (cols == 256) LBV(1, P); else if (cols == 512) LBV(2, P); else if (cols == 1024) LBV(4, P); else LBV(8, P); } while (0)
             if (dgb_partial) LBV_N(true); else LBV_N(false);
 #undef LBV_N
@@ -512,7 +530,10 @@ extern "C" int av_layernorm_bwd(const void* x, int xdt, const void* dy, int dydt
 #undef LN_BWD_N
 #undef LN_BWD
     AV_LAUNCH_CHECK();
-    if (dx_bf16) return av_cast(dx, AV_F32, dx_bf16, AV_BF16, rows * (long long)cols, stream);      // generic shapes: separate pass
+    if (dx_bf16) {                                                                                  // generic shapes: separate pass
+        if (drop_p > 0.f) return av_cast_dropout(dx, AV_F32, dx_bf16, AV_BF16, rows * (long long)cols, drop_p, drop_seed, drop_stream, stream);
+        return av_cast(dx, AV_F32, dx_bf16, AV_BF16, rows * (long long)cols, stream);
+    }
     return AV_OK;
 }
 

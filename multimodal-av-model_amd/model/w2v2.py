@@ -342,9 +342,9 @@ class Wav2Vec2ModelHIP(nn.Module):
             dh = ops.layernorm_bwd(ctx["hL"], dlast.contiguous().float(), self.P("encoder.layer_norm.weight").data, ctx["muf"], ctx["rsf"])
         else:
             dh = torch.zeros((B, T, Hd), dtype=torch.float32, device=dev)
-        # bf16 perf path without hidden dropout: the LayerNorm-backward kernels also emit the bf16 copy of dh that the next dX
-        # GEMM reads (otherwise a separate cast pass per use); dh_lp is that copy when it is current
-        fuse_lp = dtype == torch.bfloat16 and ctx["hd_p"] == 0
+        # bf16 perf path: the LayerNorm-backward kernels also emit the bf16 copy of dh that the next dX GEMM reads (otherwise a separate
+        # cast pass per use), with the hidden-dropout mask of that GEMM's site folded in; dh_lp is that copy when it is current
+        fuse_lp = dtype == torch.bfloat16
         dh_lp = None
         dmid_c = dmid.contiguous().float() if dmid is not None else None
         for li in range(nl - 1, ctx["first"] - 1, -1):
@@ -372,7 +372,7 @@ class Wav2Vec2ModelHIP(nn.Module):
                 grads[p + "feed_forward.intermediate_dense.weight"] = ops.matmul_tn(du, s["x2"].view(M, Hd))
                 grads[p + "feed_forward.intermediate_dense.bias"] = ops.colsum(du)
             r = ops.layernorm_bwd(s["h2"], dx2.view(B, T, Hd), self.P(p + "final_layer_norm.weight").data, s["mu2"], s["rs2"], dres=dh3,
-                                  want_param_grads=tr, lp_copy=fuse_lp)
+                                  want_param_grads=tr, lp_copy=fuse_lp, lp_drop=(hd_p, seed, li * 8 + 0))   # consumer: this layer's attention-output dropout
             dh2_lp = None
             if fuse_lp:
                 r, dh2_lp = r[:-1], r[-1]
@@ -403,10 +403,15 @@ class Wav2Vec2ModelHIP(nn.Module):
                 for j, n in enumerate(("q", "k", "v")):
                     grads[p + f"attention.{n}_proj.weight"] = dW[j * Hd:(j + 1) * Hd]
                     grads[p + f"attention.{n}_proj.bias"] = db[j * Hd:(j + 1) * Hd]
+            # the copy of dh serves the FFN-output dropout site of the layer below - unless that layer was dropped (LayerDrop: its site
+            # never ran, dh passes through to another site) or dmid is added to dh first (both only with dropout on)
+            lower = li - 1
+            lp_ok = fuse_lp and (hd_p == 0 or (lower >= ctx["first"] and not isinstance(ctx["saved"][lower], str)
+                                              and not (dmid_c is not None and 6 <= lower + 1 <= 9)))
             r = ops.layernorm_bwd(s["h"], dx1.view(B, T, Hd), self.P(p + "layer_norm.weight").data, s["mu1"], s["rs1"], dres=dh2,
-                                  want_param_grads=tr, lp_copy=fuse_lp)
+                                  want_param_grads=tr, lp_copy=lp_ok, lp_drop=(hd_p, seed, lower * 8 + 2))
             dh_lp = None
-            if fuse_lp:
+            if lp_ok:
                 r, dh_lp = r[:-1], r[-1]
                 r = r if tr else r[0]
             if tr:

@@ -282,8 +282,9 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, *, out_dtype: torch.dt
 
 
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
-                  want_param_grads: bool = False, lp_copy: bool = False):
-    """dx (fp32) [, dgamma, dbeta]; with ``lp_copy`` the last element returned is a bf16 copy of dx written by the same kernel."""
+                  want_param_grads: bool = False, lp_copy: bool = False, lp_drop: Optional[tuple] = None):
+    """dx (fp32) [, dgamma, dbeta]; with ``lp_copy`` the last element returned is a bf16 copy of dx written by the same kernel;
+    ``lp_drop`` = (p, seed, stream id) makes that copy dx o dropout-mask / (1 - p)."""
     cols = x.shape[-1]
     rows = x.numel() // cols
     assert x.is_contiguous() and dy.is_contiguous()
@@ -291,8 +292,13 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     dxl = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if lp_copy else None
     nblk = max(1, min(512, (rows + 15) // 16))
     part = torch.empty((nblk, 2 * cols), dtype=torch.float32, device=x.device) if want_param_grads else None
-    L.check(L.lib().av_layernorm_bwd(ptr(x), dt(x), ptr(dy), dt(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-                                     ptr(part), nblk, rows, cols, ptr(dxl), stream()), "av_layernorm_bwd")
+    if lp_copy and lp_drop is not None and lp_drop[0] > 0:
+        L.check(L.lib().av_layernorm_bwd_drop(ptr(x), dt(x), ptr(dy), dt(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                                              ptr(part), nblk, rows, cols, ptr(dxl), float(lp_drop[0]), int(lp_drop[1]), int(lp_drop[2]), stream()),
+                "av_layernorm_bwd_drop")
+    else:
+        L.check(L.lib().av_layernorm_bwd(ptr(x), dt(x), ptr(dy), dt(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                                         ptr(part), nblk, rows, cols, ptr(dxl), stream()), "av_layernorm_bwd")
     res = (dx,)
     if want_param_grads:
         gb = colsum(part)

@@ -3,10 +3,10 @@
   python tools/gemm_variants.py            -> table;   child mode: python tools/gemm_variants.py --child"""
 import importlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(12736, 3072, 1024, "plain"), (12736, 1024, 1024, "plain"), (12736, 1024, 1024, "res"), (12736, 1024, 1024, "res+drop"), (12736, 4096, 1024, "plain"),
-          (12736, 4096, 1024, "gelu+c2"), (12736, 4096, 1024, "gelu+c2+drop"), (12736, 4096, 1024, "gelugrad"), (12736, 1024, 4096, "plain"), (12736, 1024, 4096, "res"),
-          (4096, 4096, 4096, "plain"), (8192, 8192, 8192, "plain")]
-VARIANTS = [("old", {"AVAMD_GEMM_V4": "0"}), ("v4", {"AVAMD_GEMM_V4": "2"})]
+SHAPES = [(12736, 4096, 1024, "plain"), (12736, 4096, 1024, "bias"), (12736, 4096, 1024, "geluonly"), (12736, 4096, 1024, "c2only"),
+          (12736, 4096, 1024, "gelu+c2"), (12736, 4096, 1024, "gelu+c2+drop"), (12736, 4096, 1024, "plain+drop"), (12736, 4096, 1024, "gelugrad"),
+          (12736, 1024, 1024, "plain"), (12736, 1024, 1024, "res"), (12736, 1024, 1024, "res+drop")]
+VARIANTS = [("v4", {"AVAMD_GEMM_V4": "2"})]
 
 
 def child():
@@ -24,6 +24,12 @@ def child():
             kw.update(R=torch.randn(M, N, device="cuda"), bias=torch.randn(N, device="cuda")); odt = torch.float32
         if "gelu+c2" in epi:
             kw.update(bias=torch.randn(N, device="cuda"), act=L.ACT_GELU, C2=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
+        if epi == "bias":
+            kw.update(bias=torch.randn(N, device="cuda"))
+        if epi == "geluonly":
+            kw.update(bias=torch.randn(N, device="cuda"), act=L.ACT_GELU)
+        if epi == "c2only":
+            kw.update(bias=torch.randn(N, device="cuda"), C2=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
         if "gelugrad" in epi:
             kw.update(act=L.ACT_MUL_GELU_GRAD, aux=torch.randn(M, N, device="cuda").to(torch.bfloat16))
         if "drop" in epi:
