@@ -220,6 +220,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
     constexpr int TILE_BB = BNT * BK * 2;                    // B tile bytes
     constexpr int STAGE = TILE_A + TILE_BB;
     constexpr int CLD = BNT + 4;                             // fp32 epilogue image leading dimension
+    constexpr int EPI_BYTES = BM * CLD * 4;                  // the BatchNorm partial scratch (2 KiB) sits behind the image
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wrow = BNT == 128 ? (w >> 1) * 64 : w * 32;
@@ -323,6 +324,27 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 cs[(wrow + i * 16 + 4 * g + e) * CLD + wcol + j * 16 + r] = acc[i][j][e] * p.alpha;
+    if (p.stats) {
+        // train-mode BatchNorm partials (per-column sum / sum of squares over this block's rows) straight from the accumulators: rows
+        // beyond M were staged from the zero line, so they contribute exact zeros.  Lane (r, g) sums its 4 x WM_T rows of column
+        // wcol + 16 j + r, the four g groups meet through two shuffles, the wavefronts of a column range through a 2-KiB LDS scratch.
+        float* red = (float*)(smem + EPI_BYTES);
+        const int wslot = BNT == 128 ? (w >> 1) : w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = acc[i][j][e] * p.alpha; s1 += v; s2 += v * v; }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (g == 0) {
+                red[(wslot * 2) * BNT + wcol + j * 16 + r] = s1;
+                red[(wslot * 2 + 1) * BNT + wcol + j * 16 + r] = s2;
+            }
+        }
+    }
     __syncthreads();
 
     const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
@@ -445,17 +467,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
             for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C, off + e, p.out_dtype, v[e]);
         }
     }
-    if (p.stats) {   // train-mode BatchNorm partials: per-column sum / sum of squares over this block's valid rows
+    if (p.stats) {
+        // combine the two wavefronts that share a column range (partials were left in the scratch behind the image by the block above)
         if (tid < BNT && n0 + tid < p.N) {
-            float s1 = 0.f, s2 = 0.f;
-            const int rows = p.M - m0 < BM ? p.M - m0 : BM;
-            for (int rr = 0; rr < rows; ++rr) {
-                const float v = cs[rr * CLD + tid];
-                s1 += v; s2 += v * v;
-            }
+            const float* red = (const float*)(smem + EPI_BYTES);
+            constexpr int NR = BNT == 128 ? 2 : 4;            // wavefronts per column range
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) { t1 += red[(q * 2) * BNT + tid]; t2 += red[(q * 2 + 1) * BNT + tid]; }
             float* o = p.stats + (long long)mb * 2 * p.N;
-            o[n0 + tid] = s1;
-            o[p.N + n0 + tid] = s2;
+            o[n0 + tid] = t1;
+            o[p.N + n0 + tid] = t2;
         }
     }
 }
@@ -640,7 +662,7 @@ constexpr int V4_HALF = 128 * BK * 2;                       // 16 384 B: one hal
 constexpr int V4_KT = 4 * V4_HALF;                          // 65 536 B per K-tile
 constexpr int V4_CLD = V4_BN + 4;
 constexpr int V4_EPI = 128 * V4_CLD * 4;                    // 133 120 B
-constexpr int V4_LDS = 2 * V4_KT > V4_EPI ? 2 * V4_KT : V4_EPI;
+constexpr int V4_LDS = V4_EPI + 4096;                       // image (> the two K-tile rings) + BatchNorm partial scratch
 
 // Tail jobs of the v4 grid: ONE 128 x 128 quadrant of a 256 x 256 tile per workgroup (same wavefront layout: 2 x 4, 64 x 32 each, 32
 // accumulator registers).  When the tile count leaves a short last round (R = tiles mod 256 <= 128), those R tiles are cut into 4 R
@@ -739,6 +761,45 @@ __device__ __forceinline__ void v4_quadrant_job(const av_gemm_args& p, const Fas
     }
 }
 
+// implicit im2col for the v4 kernel: a half-tile is 128 output pixels, a wavefront stages 2 row groups of 8 pixels per half
+struct ConvRows2 { const bf16_t* rowp[2]; unsigned valid[2]; };
+__device__ __forceinline__ void conv_rows2_init(ConvRows2& cr, const bf16_t* __restrict__ base, const av_gemm_args& p, int mbase, int w, int lane) {
+    const int sub = lane >> 3, choff = ((lane & 7) ^ sub) << 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mbase + (w * 2 + i) * 8 + sub;
+        cr.rowp[i] = base;
+        cr.valid[i] = 0u;
+        if (m < p.M) {
+            const int ox = m % p.cOw;
+            int q = m / p.cOw;
+            const int oy = q % p.cOh;
+            q /= p.cOh;
+            const int iy0 = oy * p.cSh - p.cPh, ix0 = ox * p.cSw - p.cPw;
+            cr.rowp[i] = base + (((long long)q * p.cH + iy0) * p.cW + ix0) * p.cCtot + p.cCoff + choff;
+            unsigned v = 0u;
+            for (int ky = 0; ky < p.cKh; ++ky)
+                for (int kx = 0; kx < p.cKw; ++kx)
+                    if (iy0 + ky >= 0 && iy0 + ky < p.cH && ix0 + kx >= 0 && ix0 + kx < p.cW) v |= 1u << (ky * p.cKw + kx);
+            cr.valid[i] = v;
+        }
+    }
+}
+__device__ __forceinline__ void stage_conv2(const av_gemm_args& p, const ConvRows2& cr, int k0, char* tile, int w, int lane) {
+    const int sub = lane >> 3, pch = lane & 7;
+    const int tap = k0 / p.cCin, c0 = k0 - tap * p.cCin;
+    const int ky = tap / p.cKw, kx = tap - ky * p.cKw;
+    const long long toff = ((long long)ky * p.cW + kx) * p.cCtot + c0;          // wave-uniform
+    const bf16_t* zl = (const bf16_t*)g_zero_line + ((pch ^ sub) << 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bf16_t* src = ((cr.valid[i] >> tap) & 1u) ? cr.rowp[i] + toff : zl;
+        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 2 + i) * 1024));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+    }
+}
+
+template <bool CONV>
 __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl, const int nfull) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
@@ -791,10 +852,12 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 
     const int nk = p.K / BK;
     const int nh = 4 * nk;                                   // half-tiles in issue order: slot j = s & 3 : 0 = A0, 1 = B1, 2 = A1, 3 = B0
+    ConvRows2 cr0, cr1;                                      // CONV: tap-0 pixel pointers + in-image tap masks of my rows of A0 / A1
+    if constexpr (CONV) { conv_rows2_init(cr0, A, p, m0, w, lane); conv_rows2_init(cr1, A, p, m0 + 128, w, lane); }
     auto issue = [&](int t, int j) {                         // j is a compile-time constant at every call site
         char* slot = smem + (t & 1) * V4_KT + j * V4_HALF;
-        if (j == 0) stage_rows<2>(A, p.lda, m0, p.M, t * BK, slot, w, lane);
-        else if (j == 2) stage_rows<2>(A, p.lda, m0 + 128, p.M, t * BK, slot, w, lane);
+        if (j == 0) { if constexpr (CONV) stage_conv2(p, cr0, t * BK, slot, w, lane); else stage_rows<2>(A, p.lda, m0, p.M, t * BK, slot, w, lane); }
+        else if (j == 2) { if constexpr (CONV) stage_conv2(p, cr1, t * BK, slot, w, lane); else stage_rows<2>(A, p.lda, m0 + 128, p.M, t * BK, slot, w, lane); }
         else if (j == 3) stage_rows<2>(B, p.ldb, n0, p.N, t * BK, slot, w, lane);
         else stage_rows<2>(B, p.ldb, n0 + 128, p.N, t * BK, slot, w, lane);
     };
@@ -883,6 +946,28 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         cs[(wr * 64 + i * 16 + 4 * g + e) * V4_CLD + b * 128 + wc * 32 + j * 16 + r] = acc[half][b][i][j][e] * p.alpha;
+        if (CONV && p.stats) {
+            // train-mode BatchNorm partials from the accumulators (rows beyond M were staged from the zero line: exact zeros): lane (r, g)
+            // sums its 16 rows of column b 128 + wc 32 + 16 j + r, two shuffles join the g groups, the two wavefront rows meet in LDS
+            float* red = (float*)(smem + V4_EPI);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float v = acc[half][b][i][j][e] * p.alpha; s1 += v; s2 += v * v; }
+                    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+                    if (g == 0) {
+                        const int col = b * 128 + wc * 32 + j * 16 + r;
+                        red[(wr * 2) * 256 + col] = s1;
+                        red[(wr * 2 + 1) * 256 + col] = s2;
+                    }
+                }
+        }
         __syncthreads();
         for (int it = 0; it < 128 * CPR / V4_NT; ++it) {
             const int id = it * V4_NT + tid;
@@ -897,13 +982,20 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
             const long long off = cbase + (long long)gm * p.ldc + gn;
             epilogue_store(p, fl, v, off, gm, gn, full, R);
         }
+        if (CONV && p.stats && tid < 256 && n0 + tid < p.N && m0 + half * 128 < p.M) {
+            // row block 2 mb + half of the caller's [ceil(M / 128)][2][N] buffer: the two wavefront rows' partials (scratch behind the image)
+            const float* red = (const float*)(smem + V4_EPI);
+            float* o = p.stats + (long long)(2 * mb + half) * 2 * p.N;
+            o[n0 + tid] = red[tid] + red[512 + tid];
+            o[p.N + n0 + tid] = red[256 + tid] + red[768 + tid];
+        }
     }
 }
 
 template <int BNT, bool CONV, bool AKM = false, bool BKM = false>
 int launch_fast(const av_gemm_args& p, hipStream_t st, const FastFlags& fl) {
     constexpr int STAGE = TILE_A + BNT * BK * 2;
-    constexpr int EPI = BM * (BNT + 4) * 4;
+    constexpr int EPI = BM * (BNT + 4) * 4 + 2048;           // image + BatchNorm partial scratch
     constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
     auto kern = gemm_nt_bf16_kernel<BNT, CONV, AKM, BKM>;
     static bool attr_done = false;
@@ -959,6 +1051,22 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     static const int v4_mode = [] { const char* e = getenv("AVAMD_GEMM_V4"); return e ? atoi(e) : 1; }();
     static const int v2_mode = [] { const char* e = getenv("AVAMD_GEMM_V2"); return e ? atoi(e) : 2; }();   // 0 never, 1 always, 2 (default) when K >= 2048
     const bool v2_ok = !conv && !narrow && p.M >= 512 && (v2_mode == 1 || (v2_mode == 2 && p.K >= 2048));
+    static const int v4_conv = [] { const char* e = getenv("AVAMD_GEMM_V4_CONV"); return e ? atoi(e) : 1; }();
+    if (conv && v4_conv && v4_mode > 0 && p.N >= 256 && p.M >= 4096 && p.K >= 512 && p.batch == 1 && p.cKh * p.cKw <= 32 && p.alpha == 1.0f) {
+        // ResNet layer3 / layer4 convolutions (N = 256 / 512): implicit im2col on the 8-phase kernel
+        static bool v4c_attr = false;
+        if (!v4c_attr) {
+            if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS) != hipSuccess) {
+                av_set_error("av_gemm(fast v4 conv): cannot raise dynamic LDS to %d", V4_LDS);
+                return AV_ERR_LAUNCH;
+            }
+            v4c_attr = true;
+        }
+        const int nbM = av_cdiv(p.M, V4_BM), nbN = av_cdiv(p.N, V4_BN);
+        hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel<true>, dim3((unsigned)(nbM * nbN), 1, 1), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl, nbM * nbN);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
     if (!conv && !narrow && v4_mode > 0 && p.M >= 256 && p.N >= 256) {
         const double nk = p.K / 64.0;
         const long long t4 = (long long)av_cdiv(p.M, V4_BM) * av_cdiv(p.N, V4_BN) * p.batch;
@@ -972,7 +1080,7 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         if (v4_mode >= 2 || e4 < (v2_ok ? (e2 < e1 ? e2 : e1) : e1)) {
             static bool v4_attr = false;
             if (!v4_attr) {
-                if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS) != hipSuccess) {
+                if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS) != hipSuccess) {
                     av_set_error("av_gemm(fast v4): cannot raise dynamic LDS to %d", V4_LDS);
                     return AV_ERR_LAUNCH;
                 }
@@ -984,7 +1092,7 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
             static const int v4_tail = [] { const char* e = getenv("AVAMD_GEMM_V4_TAIL"); return e ? atoi(e) : 1; }();
             if (p.batch == 1 && v4_tail && ntile > 256 && ntile % 256 != 0 && ntile % 256 <= 128) nfull = ntile - ntile % 256;
             const unsigned nblocks = (unsigned)(nfull + 4 * (ntile - nfull));
-            hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel, dim3(nblocks, 1, (unsigned)p.batch), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl, nfull);
+            hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel<false>, dim3(nblocks, 1, (unsigned)p.batch), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl, nfull);
             AV_LAUNCH_CHECK();
             return AV_OK;
         }

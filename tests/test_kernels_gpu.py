@@ -107,9 +107,14 @@ def test_batched_strided_gemm(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Cin,Cout,H,stride,k", [(64, 64, 12, 1, 3), (64, 128, 12, 2, 3), (64, 128, 12, 2, 1), (128, 64, 6, 1, 3)])
-def test_conv2d_implicit_gemm(dtype, Cin, Cout, H, stride, k):
-    N_ = 5
+@pytest.mark.parametrize("Cin,Cout,H,stride,k,N_", [(64, 64, 12, 1, 3, 5), (64, 128, 12, 2, 3, 5), (64, 128, 12, 2, 1, 5), (128, 64, 6, 1, 3, 5),
+                                                      # ResNet layer3 / layer4 shapes on the 256 x 256 8-phase kernel (bf16, M >= 4096): ragged last
+                                                      # row tile (M = 4500 / 4509), one and two column tiles, strided + 1x1 forms
+                                                      (128, 256, 12, 2, 3, 125), (256, 256, 6, 1, 3, 125), (256, 512, 6, 2, 3, 501),
+                                                      (512, 512, 3, 1, 3, 501), (128, 256, 12, 2, 1, 125)])
+def test_conv2d_implicit_gemm(dtype, Cin, Cout, H, stride, k, N_):
+    if dtype == torch.float32 and N_ > 5:
+        pytest.skip("large shapes exercise the bf16 kernels")
     pad = k // 2
     x = _rand(N_, H, H, Cin, dtype=dtype)                       # NHWC
     w = _rand(Cout, Cin, k, k, dtype=dtype, scale=1 / math.sqrt(Cin * k * k))
