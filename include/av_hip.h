@@ -145,6 +145,21 @@ int av_attention_bwd(const void* q, const void* k, const void* v, const void* o,
                      float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int D,
                      const long long* strides, const int* klen, float scale, float drop_p, unsigned long long drop_seed,
                      unsigned int drop_stream, void* stream);
+/* Attention-probability dropout with PRECOMPUTED keep bits (whole-sequence bf16 kernels only: head_dim 64, Tq, Tk <= 256).
+ * av_attention_dropmask evaluates the (seed, stream, index) Philox masks once: mask = [B][H][ceil(Tq / 16)][64] 64-bit words, 32-byte
+ * aligned; bit 4 t + e of lane (r, g)'s word of query tile qt <-> (query 16 qt + r, key 16 t + 4 g + e).  The _mask forms of the
+ * forward and the backward read 1 bit per probability instead of evaluating the generator (once in the forward, twice in the
+ * backward).  Results are bit-identical to the calls without a mask. */
+int av_attention_dropmask(void* mask, int B, int H, int Tq, int Tk, float drop_p, unsigned long long drop_seed, unsigned int drop_stream,
+                          void* stream);
+int av_attention_fwd_mask(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H, int Tq,
+                          int Tk, int D, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
+                          long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, float drop_p,
+                          unsigned long long drop_seed, unsigned int drop_stream, const void* drop_mask, void* stream);
+int av_attention_bwd_mask(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                          float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int D,
+                          const long long* strides, const int* klen, float scale, float drop_p, unsigned long long drop_seed,
+                          unsigned int drop_stream, const void* drop_mask, void* stream);
 /* rows of the (unfused, fp32 parity mode) attention backward: P = softmax(scale*S) with key mask; dS = scale * P o (dP - sum(dP o P)) */
 int av_softmax_rows(const float* s, void* p, int pdt, long long rows, int cols, float scale, const int* klen,
                     int rows_per_batch, int ld, void* stream);

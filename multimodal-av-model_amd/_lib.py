@@ -59,6 +59,9 @@ SIGNATURES = {
     "av_mask_rows": [vp, i32, vp, ll, i32, vp],
     "av_mul_scalar_dev": [vp, vp, vp, ll, vp],
     "av_attention_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ll, ll, ll, ll, ll, ll, ll, ll, vp, f32, f32, C.c_ulonglong, C.c_uint, vp],
+    "av_attention_dropmask": [vp, i32, i32, i32, i32, f32, C.c_ulonglong, C.c_uint, vp],
+    "av_attention_fwd_mask": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ll, ll, ll, ll, ll, ll, ll, ll, vp, f32, f32, C.c_ulonglong, C.c_uint, vp, vp],
+    "av_attention_bwd_mask": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, C.c_ulonglong, C.c_uint, vp, vp],
     "av_attention_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, C.c_ulonglong, C.c_uint, vp],
     "av_softmax_rows": [vp, vp, i32, ll, i32, f32, vp, i32, i32, vp],
     "av_conv0_ln_gelu": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],

@@ -226,6 +226,14 @@ extern "C" int av_attention_fwd(const void* q, const void* k, const void* v, voi
                                 int Tk, int D, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
                                 long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, float drop_p,
                                 unsigned long long drop_seed, unsigned int drop_stream, void* stream) {
+    return av_attention_fwd_mask(q, k, v, o, lse, dtype, B, H, Tq, Tk, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, klen, scale, drop_p, drop_seed,
+                                 drop_stream, nullptr, stream);
+}
+
+extern "C" int av_attention_fwd_mask(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H, int Tq,
+                                     int Tk, int D, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
+                                     long long v_rs, long long o_bs, long long o_rs, const int* klen, float scale, float drop_p,
+                                     unsigned long long drop_seed, unsigned int drop_stream, const void* drop_mask, void* stream) {
     AV_CHECK(q && k && v && o, "av_attention_fwd: null pointer");
     AV_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0, "av_attention_fwd: bad shape B=%d H=%d Tq=%d Tk=%d", B, H, Tq, Tk);
     AV_CHECK(dtype == AV_F32 || dtype == AV_BF16, "av_attention_fwd: bad dtype %d", dtype);
@@ -236,6 +244,9 @@ extern "C" int av_attention_fwd(const void* q, const void* k, const void* v, voi
     p.scale = scale;
     AV_CHECK(drop_p >= 0.f && drop_p < 1.f, "av_attention_fwd: drop_p=%f out of [0,1)", drop_p);
     p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_stream = drop_stream;
+    AV_CHECK(!drop_mask || (dtype == AV_BF16 && D == 64 && Tq <= 256 && Tk <= 256 && (uintptr_t)drop_mask % 32 == 0),
+             "av_attention_fwd_mask: the keep-bit mask is a feature of the whole-sequence bf16 kernels (head_dim 64, T <= 256), 32-byte aligned");
+    p.dmask = (const unsigned long long*)drop_mask;
     const long long es = dtype == AV_F32 ? 4 : 2;
     auto al = [&](const void* ptr, long long bs, long long rs) {
         return ((uintptr_t)ptr % 16 == 0) && ((bs * es) % 16 == 0) && ((rs * es) % 16 == 0) && ((D * es) % 16 == 0);
@@ -245,6 +256,7 @@ extern "C" int av_attention_fwd(const void* q, const void* k, const void* v, voi
         const int rc = av_attention_short_fwd_try(p, D, (hipStream_t)stream);      // whole-sequence kernel: D = 64, T <= 256
         if (rc != AV_SHORT_NOT_TAKEN) return rc;
     }
+    AV_CHECK(!drop_mask, "av_attention_fwd_mask: the whole-sequence kernel did not take this call (alignment / AVAMD_ATTN_SHORT=0): the keep bits cannot be used");
     return dtype == AV_F32 ? dispatch_d<float>(p, D, (hipStream_t)stream) : dispatch_d<bf16_t>(p, D, (hipStream_t)stream);
 }
 

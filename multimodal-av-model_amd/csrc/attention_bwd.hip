@@ -259,6 +259,14 @@ extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, con
                                 float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int D,
                                 const long long* strides /* 16: (bs, rs) of q,k,v,o,dout,dq,dk,dv */, const int* klen, float scale,
                                 float drop_p, unsigned long long drop_seed, unsigned int drop_stream, void* stream) {
+    return av_attention_bwd_mask(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, D, strides, klen, scale, drop_p, drop_seed, drop_stream,
+                                 nullptr, stream);
+}
+
+extern "C" int av_attention_bwd_mask(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                     float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int D,
+                                     const long long* strides, const int* klen, float scale, float drop_p, unsigned long long drop_seed,
+                                     unsigned int drop_stream, const void* drop_mask, void* stream) {
     AV_CHECK(q && k && v && o && dout && lse && delta_ws && dq && dk && dv && strides, "av_attention_bwd: null pointer");
     AV_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0, "av_attention_bwd: bad shape");
     BwdP p;
@@ -273,6 +281,9 @@ extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, con
     p.scale = scale;
     AV_CHECK(drop_p >= 0.f && drop_p < 1.f, "av_attention_bwd: drop_p=%f out of [0,1)", drop_p);
     p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_stream = drop_stream;
+    AV_CHECK(!drop_mask || (D == 64 && Tq <= 256 && Tk <= 256 && (uintptr_t)drop_mask % 32 == 0),
+             "av_attention_bwd_mask: the keep-bit mask belongs to the whole-sequence kernels (head_dim 64, T <= 256), 32-byte aligned");
+    p.dmask = (const unsigned long long*)drop_mask;
     auto al = [&](const void* ptr, long long bs, long long rs) {
         return ((uintptr_t)ptr % 16 == 0) && ((bs * 2) % 16 == 0) && ((rs * 2) % 16 == 0) && ((D * 2) % 16 == 0);
     };
@@ -287,6 +298,7 @@ extern "C" int av_attention_bwd(const void* q, const void* k, const void* v, con
         const int rc = av_attention_short_bwd_try(p, D, st);       // whole-sequence kernel (attention_short.hip): D = 64, T <= 256
         if (rc != AV_SHORT_NOT_TAKEN) return rc;
     }
+    AV_CHECK(!drop_mask, "av_attention_bwd_mask: the whole-sequence kernel did not take this call: the stored mask cannot be used");
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long long)B * Tq + 3) / 4)), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout,
                        delta_ws, B, H, Tq, D, o_bs, o_rs, p.do_bs, p.do_rs);
     AV_LAUNCH_CHECK();

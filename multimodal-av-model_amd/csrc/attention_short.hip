@@ -75,8 +75,38 @@ __device__ __forceinline__ void stage_img(bf16_t* img, const bf16_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- dropout keep bits
+// One Philox evaluation per probability and step: thread = (b, h, query tile, lane (r, g)) writes the 64 keep bits of query 16 qt + r
+// for keys 16 t + 4 g + e (bit 4 t + e, t < 16) - exactly the (seed, stream, index) masks the kernels below would generate themselves
+// (index = ((b H + h) Tq + q) Tk4 + key).  The forward and both phases of the backward then read 1 bit per probability.
+__global__ __launch_bounds__(256) void attn_dropmask_kernel(uint2* __restrict__ mask, int B, int H, int Tq, int Tk, float drop_p,
+                                                            unsigned long long seed, unsigned stream_id, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int lane = (int)(i & 63), r = lane & 15, g = lane >> 4;
+    const int nqt = (Tq + 15) >> 4;
+    const long long bhq = i >> 6;
+    const int qt = (int)(bhq % nqt);
+    const long long bh = bhq / nqt;
+    const int q = qt * 16 + r;
+    unsigned lo = 0u, hi = 0u;
+    if (q < Tq) {
+        const unsigned long long base = ((unsigned long long)bh * Tq + q) * ((Tk + 3) & ~3);
+        const int nt = (Tk + 15) >> 4;
+        for (int t = 0; t < nt; ++t) {
+            float u[4];
+            drop_uniform4(seed, stream_id, base + (16 * t + 4 * g), u);
+            unsigned nib = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nib |= (u[e] >= drop_p ? 1u : 0u) << e;
+            if (t < 8) lo |= nib << (4 * t); else hi |= nib << (4 * (t - 8));
+        }
+    }
+    mask[i] = make_uint2(lo, hi);
+}
+
 // ---------------------------------------------------------------------------------------------------- forward
-template <int NKP, bool DROP>   // 32-key pairs: keys padded to 32 * NKP
+template <int NKP, int DROP>   // 32-key pairs: keys padded to 32 * NKP; DROP: 0 none, 1 generated masks, 2 precomputed keep bits
 __global__ __launch_bounds__(NT, 4) void attn_fwd_short_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = (bf16_t*)smem;
@@ -127,13 +157,24 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short_kernel(const AttnP p) {
             }
         if (DROP) {
             const float ik = 1.0f / (1.0f - p.drop_p);
-            const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * ((p.Tk + 3) & ~3);      // multiple of 4
+            if constexpr (DROP == 2) {
+                // keep bits precomputed by attn_dropmask_kernel (the same Philox masks, evaluated ONCE per step and element instead of in the
+                // forward and in both phases of the backward): bit 4 t + e of my word <-> key 16 t + 4 g + e of my query
+                const uint2 mb = ((const uint2*)p.dmask)[((((long long)b * p.H + h) * nqt + qt) << 6) + lane];
 #pragma unroll
-            for (int t = 0; t < 2 * NKP; ++t) {                // my 4 keys of tile t are consecutive and 4-aligned: ONE Philox call
-                float m4[4];
-                drop_mult4(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g), p.drop_p, ik, m4);
+                for (int t = 0; t < 2 * NKP; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) S[t][e] *= m4[e];
+                    for (int e = 0; e < 4; ++e)
+                        S[t][e] = (((4 * t + e < 32 ? mb.x : mb.y) >> ((4 * t + e) & 31)) & 1u) ? S[t][e] * ik : 0.f;
+            } else {
+                const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * ((p.Tk + 3) & ~3);      // multiple of 4
+#pragma unroll
+                for (int t = 0; t < 2 * NKP; ++t) {            // my 4 keys of tile t are consecutive and 4-aligned: ONE Philox call
+                    float m4[4];
+                    drop_mult4(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g), p.drop_p, ik, m4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[t][e] *= m4[e];
+                }
             }
         }
         sum += __shfl_xor(sum, 16, 64);
@@ -288,13 +329,14 @@ __device__ __forceinline__ void drop_quad4(unsigned long long seed, unsigned str
 }
 
 // ---------------------------------------------------------------------------------------------------- backward
-template <bool DROP>
+template <int DROP>             // 0 none, 1 generated masks, 2 precomputed keep bits
 __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int R) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* I0 = (bf16_t*)smem;                 // phase A: Q      phase B: K
     bf16_t* I1 = I0 + R * 64;                   // phase A: dO     phase B: V
     float* lse_s = (float*)(I1 + R * 64);       // [R]  log2-domain LSE of each query
     float* del_s = lse_s + R;                   // [R]  delta = sum_d dO o O
+    uint2* mask_s = (uint2*)(del_s + R);        // DROP == 2: the keep bits of this (batch, head): [query tile][lane]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b = blockIdx.y;
     int klen = p.klen ? p.klen[b] : p.Tk;
@@ -309,6 +351,8 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
     const float c = p.scale * LOG2E;
     const float ik = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const unsigned long long dbase = ((unsigned long long)b * p.H + h) * p.Tq;
+    const int nqt_m = (p.Tq + 15) >> 4;                         // stored keep bits: [b][h][query tile][lane] x 64 bits (forward kernel)
+    const long long dbase_m = ((long long)b * p.H + h) * nqt_m;
     const int RA = ((p.Tq + 31) >> 5) << 5, RB = ((p.Tk + 31) >> 5) << 5;
 
     // ---- phase A operands: Q and dO images, delta and LSE per query
@@ -338,6 +382,10 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
         }
     }
     for (int i = tid; i < R; i += NT) lse_s[i] = i < p.Tq ? lse[i] * LOG2E : 0.f;
+    if constexpr (DROP == 2) {
+        const uint2* gm = (const uint2*)p.dmask + (dbase_m << 6);
+        for (int i = tid; i < nqt_m * 64; i += NT) mask_s[i] = gm[i];
+    }
     __syncthreads();
 
     // ---- phase A: a wavefront owns 16 keys; S = Q K^T has the key on the lane, 4 queries in the registers
@@ -363,7 +411,23 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
                 dp = mfma(row_frag(I1, q0 + r, 4 + g), vf1, dp);
                 const f32x4 l4 = *(const f32x4*)(lse_s + q0 + 4 * g), d4 = *(const f32x4*)(del_s + q0 + 4 * g);
                 float dm[4] = {1.f, 1.f, 1.f, 1.f};
-                if (DROP) drop_quad4(p.drop_seed, p.drop_stream, (dbase + q0 + 4 * g) * ((p.Tk + 3) & ~3), (unsigned long long)((p.Tk + 3) & ~3), krow, r, p.drop_p, ik, dm);
+                if (DROP) {
+                    if constexpr (DROP == 2) {
+                        // forward layout: query tile q0 / 16, lane' = (r' = query % 16 = 4 g + e, g' = (key % 16) / 4 = r >> 2), bit 4 kt + (key & 3):
+                        // my four queries are four consecutive 64-bit words
+                        const int qt_ = (q0 >> 4) < nqt_m ? (q0 >> 4) : nqt_m - 1;
+                        const uint4* mp = (const uint4*)(mask_s + ((qt_ << 6) + ((r >> 2) << 4) + 4 * g));
+                        const uint4 w01 = mp[0], w23 = mp[1];
+                        const int bit = 4 * kt + (r & 3);
+                        const bool lo = bit < 32;
+                        const int sh = bit & 31;
+                        const unsigned s0 = (lo ? w01.x : w01.y) >> sh, s1 = (lo ? w01.z : w01.w) >> sh;
+                        const unsigned s2 = (lo ? w23.x : w23.y) >> sh, s3 = (lo ? w23.z : w23.w) >> sh;
+                        dm[0] = (s0 & 1u) ? ik : 0.f; dm[1] = (s1 & 1u) ? ik : 0.f; dm[2] = (s2 & 1u) ? ik : 0.f; dm[3] = (s3 & 1u) ? ik : 0.f;
+                    } else {
+                        drop_quad4(p.drop_seed, p.drop_stream, (dbase + q0 + 4 * g) * ((p.Tk + 3) & ~3), (unsigned long long)((p.Tk + 3) & ~3), krow, r, p.drop_p, ik, dm);
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int q = q0 + 4 * g + e;
@@ -408,6 +472,8 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
         const bf16x8 of0 = *(const bf16x8*)(DO + qld * p.do_rs + 8 * g), of1 = *(const bf16x8*)(DO + qld * p.do_rs + 32 + 8 * g);
         const bool qok = qrow < p.Tq;
         const float lq = lse_s[qrow], dq_ = del_s[qrow];
+        const uint2 mb2 = DROP == 2 ? mask_s[(qt << 6) + lane] : make_uint2(0u, 0u);                   // my query's keep bits
+        const unsigned long long mbits = ((unsigned long long)mb2.y << 32) | mb2.x;
         f32x4 dQt[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) dQt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -422,7 +488,15 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
                 dp = mfma(row_frag(I1, k0 + r, g), of0, dp);
                 dp = mfma(row_frag(I1, k0 + r, 4 + g), of1, dp);
                 float m4[4] = {1.f, 1.f, 1.f, 1.f};
-                if (DROP) drop_mult4(p.drop_seed, p.drop_stream, (dbase + qrow) * ((p.Tk + 3) & ~3) + (k0 + 4 * g), p.drop_p, ik, m4);
+                if (DROP) {
+                    if constexpr (DROP == 2) {
+                        const unsigned nib = (unsigned)(mbits >> (4 * (2 * tp + hf))) & 15u;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m4[e] = ((nib >> e) & 1u) ? ik : 0.f;
+                    } else {
+                        drop_mult4(p.drop_seed, p.drop_stream, (dbase + qrow) * ((p.Tk + 3) & ~3) + (k0 + 4 * g), p.drop_p, ik, m4);
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int key = k0 + 4 * g + e;
@@ -652,7 +726,7 @@ bool short_enabled() {
 
 bool al8(const void* ptr, long long bs, long long rs) { return ((uintptr_t)ptr % 8 == 0) && (bs % 4 == 0) && (rs % 4 == 0); }
 
-template <int NKP, bool DROP>
+template <int NKP, int DROP>
 int launch_fwd_short2(const AttnP& p, hipStream_t st) {
     const int lds = 2 * NKP * 32 * 64 * 2;
     static bool done = false;
@@ -669,14 +743,14 @@ int launch_fwd_short2(const AttnP& p, hipStream_t st) {
 }
 template <int NKP>
 int launch_fwd_short(const AttnP& p, hipStream_t st) {
-    return p.drop_p > 0.f ? launch_fwd_short2<NKP, true>(p, st) : launch_fwd_short2<NKP, false>(p, st);
+    return p.drop_p > 0.f ? (p.dmask ? launch_fwd_short2<NKP, 2>(p, st) : launch_fwd_short2<NKP, 1>(p, st)) : launch_fwd_short2<NKP, 0>(p, st);
 }
 
-template <bool DROP>
+template <int DROP>
 int launch_bwd_short(const BwdP& p, int R, int lds, hipStream_t st) {
     static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute((const void*)attn_bwd_short_kernel<DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 64 * 2 + 2 * 256 * 4) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_short_kernel<DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 64 * 2 + 2 * 256 * 4 + 16 * 64 * 8) != hipSuccess) {
             av_set_error("av_attention_bwd: cannot raise dynamic LDS");
             return AV_ERR_LAUNCH;
         }
@@ -745,6 +819,17 @@ int av_attention_short_bwd_try(const BwdP& p, int D, hipStream_t st) {
     }
     const int tmax = p.Tq > p.Tk ? p.Tq : p.Tk;
     const int R = (tmax + 31) / 32 * 32;
-    const int lds = 2 * R * 64 * 2 + 2 * R * 4;
-    return p.drop_p > 0.f ? launch_bwd_short<true>(p, R, lds, st) : launch_bwd_short<false>(p, R, lds, st);
+    const int lds = 2 * R * 64 * 2 + 2 * R * 4 + (p.drop_p > 0.f && p.dmask ? ((p.Tq + 15) / 16) * 64 * 8 : 0);      // + the (b, h) keep bits
+    return p.drop_p > 0.f ? (p.dmask ? launch_bwd_short<2>(p, R, lds, st) : launch_bwd_short<1>(p, R, lds, st)) : launch_bwd_short<0>(p, R, lds, st);
+}
+
+extern "C" int av_attention_dropmask(void* mask, int B, int H, int Tq, int Tk, float drop_p, unsigned long long drop_seed, unsigned int drop_stream,
+                                     void* stream) {
+    AV_CHECK(mask && B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tq <= 256 && Tk <= 256 && drop_p > 0.f && drop_p < 1.f && (uintptr_t)mask % 32 == 0,
+             "av_attention_dropmask: bad args (Tq=%d Tk=%d p=%f; T <= 256, mask 32-byte aligned)", Tq, Tk, drop_p);
+    const long long n = (long long)B * H * ((Tq + 15) / 16) * 64;
+    hipLaunchKernelGGL(attn_dropmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint2*)mask, B, H, Tq, Tk, drop_p,
+                       drop_seed, drop_stream, n);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
 }

@@ -15,6 +15,7 @@ struct AttnP {
     float drop_p;                 // attention-probability dropout (hf:457): P*mask/(1-p) feeds PV, the softmax sum is undropped
     unsigned drop_stream;
     unsigned long long drop_seed;
+    const unsigned long long* dmask;   // optional: precomputed keep bits (attn_dropmask_kernel, attention_short.hip) read instead of Philox
 };
 
 // Attention-probability dropout: element (b, h, q, k) uses Philox element index ((b H + h) Tq + q) * Tk4 + k with the row pitch
@@ -31,6 +32,7 @@ struct BwdP {
     float drop_p;
     unsigned drop_stream;
     unsigned long long drop_seed;
+    const unsigned long long* dmask;   // optional: the same precomputed keep bits
 };
 
 // whole-sequence kernels for short sequences (attention_short.hip); AV_SHORT_NOT_TAKEN = shape not covered, caller goes on

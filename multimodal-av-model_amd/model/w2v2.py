@@ -27,6 +27,8 @@ from ..utils import init as _init
 from ..utils.shadow import ParamCache
 
 Tensor = torch.Tensor
+# attention-dropout keep bits evaluated once per step on a side stream (0: every kernel generates its masks itself; A/B runs)
+DROP_BITS = os.environ.get("AVAMD_ATTN_DROPBITS", "1") != "0"
 
 
 def param_shapes(cfg: dict) -> Dict[str, tuple]:
@@ -284,6 +286,23 @@ class Wav2Vec2ModelHIP(nn.Module):
             h = ops.cast_dropout(h, torch.float32, (hd_p, seed, S_POS))                  # hf:765
         train = self.trainable_layers() if save else [False] * nl
         first = train.index(True) if any(train) else nl
+        # LayerDrop decisions (hf:774-789), drawn up front in layer order (the same draws the loop would make)
+        dropped = [bool(ld_p > 0 and float(torch.rand([], generator=self.layerdrop_generator)) < ld_p) for _ in range(nl)]
+        # Attention-dropout keep bits of the layers that get a backward: ONE generator evaluation per probability (instead of one in the
+        # forward and two in the backward), on a side stream - the kernels depend on no data and are pure VALU work beside the GEMMs
+        amasks, amask_evt = {}, None
+        if at_p > 0 and save and first < nl and dev.type == "cuda" and DROP_BITS and ops.attention_mask_shape_ok(dtype, B, T, T, hd):
+            if getattr(self, "_mask_stream", None) is None:
+                self._mask_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            self._mask_stream.wait_stream(main)
+            with torch.cuda.stream(self._mask_stream):
+                for li in range(first, nl):
+                    if not dropped[li]:
+                        amasks[li] = ops.attention_dropmask(B, nh, T, T, (at_p, seed, li * 8 + 3), dev)
+            amask_evt = torch.cuda.Event(); amask_evt.record(self._mask_stream)
+            for m in amasks.values():
+                m.record_stream(main)
         mid = torch.zeros_like(h) if nl >= 10 else None
         saved = [None] * nl
         scale = hd ** -0.5
@@ -292,15 +311,19 @@ class Wav2Vec2ModelHIP(nn.Module):
                 ops.axpby(0.25, h, 1.0, mid)                                             # model/encoder.py:97-99
             p = f"encoder.layers.{li}."
             keep_ctx = save and li >= first
-            if ld_p > 0 and float(torch.rand([], generator=self.layerdrop_generator)) < ld_p:    # LayerDrop (hf:774-789): identity layer
+            if dropped[li]:                                                              # LayerDrop (hf:774-789): identity layer
                 if keep_ctx:
                     saved[li] = "skipped"
                 continue
             x1, mu1, rs1 = ops.layernorm_fwd(h, self.P(p + "layer_norm.weight").data, self.P(p + "layer_norm.bias").data,
                                              out_dtype=dtype, eps=eps, save_stats=True)
             qkv = ops.linear(x1, self.qkv_w(li, dtype), self.qkv_b(li), out_dtype=dtype).view(B, T, 3, nh, hd)
+            amask = amasks.get(li)
+            if amask is not None and amask_evt is not None:
+                torch.cuda.current_stream(dev).wait_event(amask_evt)
+                amask_evt = None
             ao, lse = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], klen, scale, need_lse=keep_ctx,
-                                        drop=(at_p, seed, li * 8 + 3))
+                                        drop=(at_p, seed, li * 8 + 3), drop_mask=amask)
             h2 = ops.linear(ao.view(B, T, Hd), self.c(p + "attention.out_proj.weight", dtype), self.P(p + "attention.out_proj.bias").data,
                             out_dtype=torch.float32, R=h, drop=(hd_p, seed, li * 8 + 0))
             x2, mu2, rs2 = ops.layernorm_fwd(h2, self.P(p + "final_layer_norm.weight").data, self.P(p + "final_layer_norm.bias").data,
@@ -313,7 +336,7 @@ class Wav2Vec2ModelHIP(nn.Module):
                             out_dtype=torch.float32, R=h2, drop=(hd_p, seed, li * 8 + 2))
             if keep_ctx:
                 tr = train[li]
-                saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, lse=lse, h2=h2, mu2=mu2, rs2=rs2, u=u,
+                saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, lse=lse, amask=amask, h2=h2, mu2=mu2, rs2=rs2, u=u,
                                  x1=x1 if tr else None, x2=x2 if tr else None, g=g if tr else None)
             h = h3
         last, muf, rsf = ops.layernorm_fwd(h, self.P("encoder.layer_norm.weight").data, self.P("encoder.layer_norm.bias").data,
@@ -395,7 +418,7 @@ class Wav2Vec2ModelHIP(nn.Module):
             qkv = s["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dao, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx["klen"], scale,
-                              o=s["ao"], lse=s["lse"], drop=(at_p, seed, li * 8 + 3))
+                              o=s["ao"], lse=s["lse"], drop=(at_p, seed, li * 8 + 3), drop_mask=s["amask"])
             dx1 = ops.matmul_nn(dqkv.view(M, 3 * Hd), self.qkv_w(li, dtype), out_dtype=dtype, b_is_weight=True)
             if tr:
                 dW = ops.matmul_tn(dqkv.view(M, 3 * Hd), s["x1"].view(M, Hd))

@@ -374,8 +374,23 @@ def _chk_view(t: Tensor, name: str):
         raise ValueError(f"{name}: expected a [B,T,H,D] view with contiguous D and head stride D, got {tuple(t.shape)} / {t.stride()}")
 
 
+_ATTN_SHORT = os.environ.get("AVAMD_ATTN_SHORT", "1") != "0"
+
+
+def attention_mask_shape_ok(dtype, B: int, Tq: int, Tk: int, D: int) -> bool:
+    return _ATTN_SHORT and dtype == torch.bfloat16 and D == 64 and Tq <= 256 and Tk <= 256 and B <= 65535
+
+
+def attention_dropmask(B: int, H: int, Tq: int, Tk: int, drop: tuple, device) -> Tensor:
+    """Keep bits of the attention-probability dropout of a [B, H, Tq, Tk] problem, evaluated once for the whole-sequence forward and both
+    phases of its backward (check ``attention_mask_shape_ok`` first)."""
+    mask = torch.empty((B, H, (Tq + 15) // 16, 64), dtype=torch.int64, device=device)
+    L.check(L.lib().av_attention_dropmask(ptr(mask), B, H, Tq, Tk, float(drop[0]), int(drop[1]), int(drop[2]), stream()), "av_attention_dropmask")
+    return mask
+
+
 def attention_fwd(q: Tensor, k: Tensor, v: Tensor, klen: Optional[Tensor], scale: float, need_lse: bool = True,
-                  drop: Optional[tuple] = None):
+                  drop: Optional[tuple] = None, drop_mask: Optional[Tensor] = None):
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk_view(t, n)
     B, Tq, H, D = q.shape
@@ -385,9 +400,10 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, klen: Optional[Tensor], scale
     dp, dseed, dstream = (float(drop[0]), int(drop[1]), int(drop[2])) if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
     es = q.element_size()
     _probed(f"fwd{D}", 4.0 * B * H * Tq * Tk * D, B * H * D * es * (2 * Tq + 2 * Tk),
-            lambda: L.check(L.lib().av_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), dt(q), B, H, Tq, Tk, D,
-                                                     q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                                     o.stride(0), o.stride(1), ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_fwd"))
+            lambda: L.check(L.lib().av_attention_fwd_mask(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), dt(q), B, H, Tq, Tk, D,
+                                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                                          o.stride(0), o.stride(1), ptr(klen), scale, dp, dseed, dstream,
+                                                          ptr(drop_mask) if dp > 0 else None, stream()), "av_attention_fwd"))
     return o, lse
 
 
@@ -410,7 +426,8 @@ def fusion_xattn_fwd(a: Tensor, v: Tensor, w_in: Tensor, b_in: Tensor, nh: int, 
 
 
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: Tensor, dv: Tensor, klen: Optional[Tensor],
-                  scale: float, o: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop: Optional[tuple] = None) -> None:
+                  scale: float, o: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop: Optional[tuple] = None,
+                  drop_mask: Optional[Tensor] = None) -> None:
     """Backward of attention_fwd from batched MFMA GEMMs + row kernels (P is re-materialised, T x T is small here):
     P = softmax(scale QK^T); dV = P^T dO; dP = dO V^T; dS = scale P o (dP - rowsum(dP o P)); dQ = dS K; dK = dS^T Q.
     dq/dk/dv are [B,T,H,D] output views (written in place)."""
@@ -425,8 +442,9 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: T
         delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
         es = q.element_size()
         _probed(f"bwd{D}", 10.0 * B * H * Tq * Tk * D, B * H * D * es * (4 * Tq + 4 * Tk),
-                lambda: L.check(L.lib().av_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                                                         B, H, Tq, Tk, D, st, ptr(klen), scale, dp, dseed, dstream, stream()), "av_attention_bwd"))
+                lambda: L.check(L.lib().av_attention_bwd_mask(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                                              B, H, Tq, Tk, D, st, ptr(klen), scale, dp, dseed, dstream,
+                                                              ptr(drop_mask) if dp > 0 else None, stream()), "av_attention_bwd"))
         return
     # unfused form (fp32 parity mode).  With dropout the row pitch equals the Philox row pitch of the attention kernels (keys padded
     # to 4, attn_common.h), so the mask of element (b, h, q, k) is the mask of linear index row * ld + k of these buffers

@@ -76,6 +76,31 @@ def test_attention_dropout_fwd_bwd_same_mask(B, H, T, D, dtype):
         torch.testing.assert_close(a.float().permute(0, 2, 1, 3), g, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("B,H,T", [(2, 4, 70), (3, 16, 199), (1, 2, 256), (2, 3, 33)])
+def test_attention_precomputed_dropout_bits_equal_generated_masks(B, H, T):
+    """Keep bits evaluated once (av_attention_dropmask) and read by the whole-sequence forward and by both phases of the backward must
+    give, bit for bit, the results of the kernels generating the Philox masks themselves."""
+    ops = pkg("ops")
+    D = 64
+    qkv = torch.randn(B, T, 3, H, D, device="cuda").to(torch.bfloat16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    klen = torch.tensor([T, max(1, T - 9), max(1, T // 2)][:B], device="cuda", dtype=torch.int32)
+    dr = (0.2, 99, 5)
+    assert ops.attention_mask_shape_ok(q.dtype, B, T, T, D)
+    mask = ops.attention_dropmask(B, H, T, T, dr, q.device)
+    assert mask.shape == (B, H, (T + 15) // 16, 64)
+    o, lse = ops.attention_fwd(q, k, v, klen, D ** -0.5, drop=dr, drop_mask=mask)
+    o2, lse2 = ops.attention_fwd(q, k, v, klen, D ** -0.5, drop=dr)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    do = torch.randn(B, T, H, D, device="cuda").to(torch.bfloat16)
+    outs = []
+    for m in (mask, None):
+        d = torch.zeros_like(qkv)
+        ops.attention_bwd(q, k, v, do, d[:, :, 0], d[:, :, 1], d[:, :, 2], klen, D ** -0.5, o=o, lse=lse, drop=dr, drop_mask=m)
+        outs.append(d)
+    assert torch.equal(outs[0], outs[1])
+
+
 def _audio(cfg_extra, precision):
     init = pkg("utils.init"); enc = pkg("model.encoder"); synth = pkg("dataset.synthetic")
     pkg("precision").set_precision(precision)

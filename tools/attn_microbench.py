@@ -25,7 +25,10 @@ for (B, H, T, D) in [(32, 16, 199, 64), (64, 16, 199, 64), (2, 16, 49, 64), (8, 
         ops.attention_bwd(q, k, v, do, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], klen, scale, o=o, lse=lse, drop=drop)
 
     dr = (0.1, 1234, 3)
-    for name, fn, fl in (("fwd", fwd, 4.0 * B * H * T * T * D), ("bwd", bwd, 10.0 * B * H * T * T * D),
+    mk = ops.attention_dropmask(B, H, T, T, dr, q.device) if T <= 256 else None
+    for name, fn, fl in (("keep-bit kernel", lambda: ops.attention_dropmask(B, H, min(T, 256), min(T, 256), dr, q.device), 0.0),
+                         ("fwd+dropout (bits)", lambda: ops.attention_fwd(q, k, v, klen, scale, drop=dr, drop_mask=mk), 4.0 * B * H * T * T * D),
+                         ("bwd+dropout (bits)", lambda: ops.attention_bwd(q, k, v, do, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], klen, scale, o=o, lse=lse, drop=dr, drop_mask=mk), 10.0 * B * H * T * T * D),("fwd", fwd, 4.0 * B * H * T * T * D), ("bwd", bwd, 10.0 * B * H * T * T * D),
                          ("fwd+dropout", lambda: fwd(dr), 4.0 * B * H * T * T * D), ("bwd+dropout", lambda: bwd(dr), 10.0 * B * H * T * T * D)):
         for _ in range(3):
             fn()
@@ -36,4 +39,4 @@ for (B, H, T, D) in [(32, 16, 199, 64), (64, 16, 199, 64), (2, 16, 49, 64), (8, 
             fn()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / 20
-        print(f"B={B} H={H} T={T} D={D} {name:12s}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+        print(f"B={B} H={H} T={T} D={D} {name:24s}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
