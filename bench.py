@@ -269,13 +269,13 @@ def main():
                 if args.precision == "bf16" and os.path.exists(pmc):
                     tb = tl = 0                                                         # launch-weighted over the tilings of the family
                     for kname, kv in json.load(open(pmc))["kernels"].items():
-                        if "gemm_nt_bf16_kernel<128, false, false, false>" in kname or "gemm_nt_bf16_v2_kernel" in kname or "gemm_nt_bf16_v3_kernel" in kname:
+                        if "gemm_nt_bf16_kernel<128, false, false, false>" in kname or "gemm_nt_bf16_v2_kernel" in kname or "gemm_nt_bf16_v4_kernel<false>" in kname:
                             tb += kv["launches"] * (kv["fetch_bytes_per_launch"] + kv["write_bytes_per_launch"]); tl += kv["launches"]
                     traffic, tsrc = (round(tb / tl) if tl else None), cand
                     break
             n = len(probe["records"])
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16 family (row-major NT products: every nn.Linear forward, dX through cached W^T, strided conv1d)" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>"),
+            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_v4_kernel (256x256x64 8-phase) + the 128x128 / 256x128 tilings of the same family: row-major NT products = every nn.Linear forward, dX through cached W^T, strided conv1d" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_note": f"HBM-side bytes per launch from profiles/{tsrc} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                     "algorithmic_bytes_per_launch": round(tot_by / n),
