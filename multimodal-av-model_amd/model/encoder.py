@@ -58,6 +58,14 @@ class AudioEncoder(nn.Module):
             raise RuntimeError("AudioEncoder (HIP): input must be on the GPU; there is no CPU fallback")
         return w2v2_apply(self.model, x, attention_mask)
 
+    def forward_pair(self, x: torch.Tensor, attention_mask1: Optional[torch.Tensor], attention_mask2: Optional[torch.Tensor]):
+        """The reference's two calls ``audio_encoder(audio, mask1)`` / ``audio_encoder(audio, mask2)`` (model/trainer.py:94-95) as one
+        autograd node -> (last1, mid1, last2, mid2): same values, but the two backward passes run layer by layer with their weight
+        gradients accumulated in place (one gradient bucket per layer and step under data parallelism)."""
+        if not x.is_cuda:
+            raise RuntimeError("AudioEncoder (HIP): input must be on the GPU; there is no CPU fallback")
+        return w2v2_apply(self.model, x, attention_mask1, attention_mask2, two_passes=True)
+
 
 # ---------------------------------------------------------------------------------------------------------------
 # Visual encoder (model/encoder.py:6-75): Conv3d front-end + ResNet-18 trunk, BatchNorm + PReLU, applied per frame.

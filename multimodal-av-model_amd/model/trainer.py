@@ -214,10 +214,10 @@ class MultimodalTrainer:
         if passes == 2:
             self.audio_encoder.model._feat_cache = {}              # both passes read the same waveform: one conv feature-extractor run
         try:
-            a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1)
             if passes == 2:
-                a2, mid2 = self.audio_encoder(d["audio"], attention_mask=(d["mask2"] != 3))
+                a1, mid1, a2, mid2 = self.audio_encoder.forward_pair(d["audio"], attn1, d["mask2"] != 3)
             else:
+                a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1)
                 a2, mid2 = a1, mid1
         finally:
             self.audio_encoder.model._feat_cache = None

@@ -352,6 +352,45 @@ class Wav2Vec2ModelHIP(nn.Module):
     # ---- backward --------------------------------------------------------------------------------------------
     def backward(self, ctx: dict, dlast: Optional[Tensor], dmid: Optional[Tensor]) -> Dict[str, Tensor]:
         """Gradients of the trainable encoder-layer parameters given d(last_hidden_state) and d(mid)."""
+        return self.backward_multi([ctx], [dlast], [dmid])
+
+    def backward_multi(self, ctxs: List[dict], dlasts: List[Optional[Tensor]], dmids: List[Optional[Tensor]]) -> Dict[str, Tensor]:
+        """Backward of several forward passes over the SAME parameters (the reference's two audio passes per step, model/trainer.py:94-95)
+        walked layer by layer: for every layer the passes run one after the other and the later ones ACCUMULATE their weight gradients into
+        the first one's buffers (GEMM / column-sum accumulate forms: no separate gradient-sum pass), so that under data parallelism a layer's
+        gradients leave in ONE bucket per step instead of one per pass."""
+        cfg = self.cfg
+        nl = cfg["num_hidden_layers"]
+        Hd = cfg["hidden_size"]
+        grads: Dict[str, Tensor] = {}
+        states = []
+        for ctx, dlast, dmid in zip(ctxs, dlasts, dmids):
+            B, T = ctx["B"], ctx["T"]
+            dev = ctx["hL"].device
+            if dlast is not None:
+                dh = ops.layernorm_bwd(ctx["hL"], dlast.contiguous().float(), self.P("encoder.layer_norm.weight").data, ctx["muf"], ctx["rsf"])
+            else:
+                dh = torch.zeros((B, T, Hd), dtype=torch.float32, device=dev)
+            # dh_lp: bf16 copy of dh (with the hidden-dropout mask of the consuming site folded in) when it is current
+            states.append(dict(dh=dh, dh_lp=None, dmid=dmid.contiguous().float() if dmid is not None else None))
+        first = min(c["first"] for c in ctxs)
+        for li in range(nl - 1, first - 1, -1):
+            p = f"encoder.layers.{li}."
+            for ctx, st in zip(ctxs, states):
+                if li >= ctx["first"]:
+                    self._layer_backward(ctx, st, li, grads)
+            if self.grad_ready is not None:                         # the layer's gradients (all passes) go out while the next layer's backward runs
+                keys = [k for k in grads if k.startswith(p)]
+                if keys:
+                    for k, v in zip(keys, self.grad_ready([grads[k] for k in keys])):
+                        grads[k] = v
+        if self.grad_wait is not None:
+            self.grad_wait()
+        return grads
+
+    def _layer_backward(self, ctx: dict, st: dict, li: int, grads: Dict[str, Tensor]) -> None:
+        """One encoder layer of one pass: updates st['dh'] (gradient of the residual stream below the layer) and adds the layer's weight
+        gradients to ``grads`` (created on first use, accumulated in place afterwards)."""
         cfg = self.cfg
         dtype = ctx["dtype"]
         B, T = ctx["B"], ctx["T"]
@@ -359,119 +398,140 @@ class Wav2Vec2ModelHIP(nn.Module):
         hd = Hd // nh
         nl = cfg["num_hidden_layers"]
         scale = hd ** -0.5
-        grads: Dict[str, Tensor] = {}
-        dev = ctx["hL"].device
-        if dlast is not None:
-            dh = ops.layernorm_bwd(ctx["hL"], dlast.contiguous().float(), self.P("encoder.layer_norm.weight").data, ctx["muf"], ctx["rsf"])
-        else:
-            dh = torch.zeros((B, T, Hd), dtype=torch.float32, device=dev)
-        # bf16 perf path: the LayerNorm-backward kernels also emit the bf16 copy of dh that the next dX GEMM reads (otherwise a separate
-        # cast pass per use), with the hidden-dropout mask of that GEMM's site folded in; dh_lp is that copy when it is current
         fuse_lp = dtype == torch.bfloat16
+        dh, dh_lp, dmid_c = st["dh"], st["dh_lp"], st["dmid"]
+        if dmid_c is not None and 6 <= li + 1 <= 9 and li + 1 < nl:
+            ops.axpby(0.25, dmid_c, 1.0, dh)
+            dh_lp = None                                             # dh changed after its bf16 copy was written
+        s = ctx["saved"][li]
+        if isinstance(s, str):                                       # LayerDrop skipped this layer: identity
+            st["dh_lp"] = dh_lp
+            return
+        tr = ctx["train"][li]
+        p = f"encoder.layers.{li}."
+        M = B * T
+        seed, hd_p, at_p, ac_p = ctx["seed"], ctx["hd_p"], ctx["at_p"], ctx["ac_p"]
+
+        def wgrad(key, dy, x):                                       # dW (+)= dy^T x
+            if key in grads:
+                ops.matmul_tn(dy, x, out=grads[key], accumulate=True)
+            else:
+                grads[key] = ops.matmul_tn(dy, x)
+
+        def bgrad(key, dy):                                          # db (+)= column sums
+            if key in grads:
+                ops.colsum(dy, out=grads[key], accumulate=True)
+            else:
+                grads[key] = ops.colsum(dy)
+
+        dh3 = dh
+        dh3_t = dh_lp if (fuse_lp and dh_lp is not None) else ops.cast_dropout(dh3, dtype, (hd_p, seed, li * 8 + 2))   # FFN-output dropout mask
+        W2 = self.c(p + "feed_forward.output_dense.weight", dtype)            # [Hd, I]
+        du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I), b_is_weight=True,
+                           drop=(ac_p, seed, li * 8 + 1))
+        if tr:
+            wgrad(p + "feed_forward.output_dense.weight", dh3_t.view(M, Hd), s["g"].view(M, I))
+            bgrad(p + "feed_forward.output_dense.bias", (dh3_t if hd_p > 0 else dh3).view(M, Hd))
+        W1 = self.c(p + "feed_forward.intermediate_dense.weight", dtype)      # [I, Hd]
+        dx2 = ops.matmul_nn(du, W1, out_dtype=dtype, b_is_weight=True)
+        if tr:
+            wgrad(p + "feed_forward.intermediate_dense.weight", du, s["x2"].view(M, Hd))
+            bgrad(p + "feed_forward.intermediate_dense.bias", du)
+        ln2 = p + "final_layer_norm."
+        r = ops.layernorm_bwd(s["h2"], dx2.view(B, T, Hd), self.P(ln2 + "weight").data, s["mu2"], s["rs2"], dres=dh3,
+                              want_param_grads=tr, lp_copy=fuse_lp, lp_drop=(hd_p, seed, li * 8 + 0),   # consumer: this layer's attention-output dropout
+                              gb_acc=grads.get(ln2 + "_gb") if tr else None, packed_gb=True)
+        dh2_lp = None
+        if fuse_lp:
+            r, dh2_lp = r[:-1], r[-1]
+            r = r if tr else r[0]
+        if tr:
+            dh2, gb = r
+            grads[ln2 + "_gb"] = gb
+        else:
+            dh2 = r
+        dh2_t = dh2_lp if dh2_lp is not None else ops.cast_dropout(dh2, dtype, (hd_p, seed, li * 8 + 0))
+        Wo = self.c(p + "attention.out_proj.weight", dtype)
+        dao = ops.matmul_nn(dh2_t.view(M, Hd), Wo, out_dtype=dtype, b_is_weight=True).view(B, T, nh, hd)
+        if tr:
+            wgrad(p + "attention.out_proj.weight", dh2_t.view(M, Hd), s["ao"].view(M, Hd))
+            bgrad(p + "attention.out_proj.bias", (dh2_t if hd_p > 0 else dh2).view(M, Hd))
+        qkv = s["qkv"]
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dao, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx["klen"], scale,
+                          o=s["ao"], lse=s["lse"], drop=(at_p, seed, li * 8 + 3), drop_mask=s["amask"])
+        dx1 = ops.matmul_nn(dqkv.view(M, 3 * Hd), self.qkv_w(li, dtype), out_dtype=dtype, b_is_weight=True)
+        if tr:
+            wgrad(p + "attention._qkv_w", dqkv.view(M, 3 * Hd), s["x1"].view(M, Hd))      # packed [3 Hd, Hd]: split into q / k / v at the end
+            bgrad(p + "attention._qkv_b", dqkv.view(M, 3 * Hd))
+        # the copy of dh serves the FFN-output dropout site of the layer below - unless that layer was dropped (LayerDrop: its site
+        # never ran, dh passes through to another site) or dmid is added to dh first (both only with dropout on)
+        lower = li - 1
+        lp_ok = fuse_lp and (hd_p == 0 or (lower >= ctx["first"] and not isinstance(ctx["saved"][lower], str)
+                                          and not (dmid_c is not None and 6 <= lower + 1 <= 9)))
+        ln1 = p + "layer_norm."
+        r = ops.layernorm_bwd(s["h"], dx1.view(B, T, Hd), self.P(ln1 + "weight").data, s["mu1"], s["rs1"], dres=dh2,
+                              want_param_grads=tr, lp_copy=lp_ok, lp_drop=(hd_p, seed, lower * 8 + 2),
+                              gb_acc=grads.get(ln1 + "_gb") if tr else None, packed_gb=True)
         dh_lp = None
-        dmid_c = dmid.contiguous().float() if dmid is not None else None
-        for li in range(nl - 1, ctx["first"] - 1, -1):
-            if dmid_c is not None and 6 <= li + 1 <= 9 and li + 1 < nl:
-                ops.axpby(0.25, dmid_c, 1.0, dh)
-                dh_lp = None                                         # dh changed after its bf16 copy was written
-            s = ctx["saved"][li]
-            if isinstance(s, str):                                   # LayerDrop skipped this layer: identity
-                continue
-            tr = ctx["train"][li]
-            p = f"encoder.layers.{li}."
-            M = B * T
-            seed, hd_p, at_p, ac_p = ctx["seed"], ctx["hd_p"], ctx["at_p"], ctx["ac_p"]
-            dh3 = dh
-            dh3_t = dh_lp if (fuse_lp and dh_lp is not None) else ops.cast_dropout(dh3, dtype, (hd_p, seed, li * 8 + 2))   # FFN-output dropout mask
-            W2 = self.c(p + "feed_forward.output_dense.weight", dtype)            # [Hd, I]
-            du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I), b_is_weight=True,
-                               drop=(ac_p, seed, li * 8 + 1))
-            if tr:
-                grads[p + "feed_forward.output_dense.weight"] = ops.matmul_tn(dh3_t.view(M, Hd), s["g"].view(M, I))
-                grads[p + "feed_forward.output_dense.bias"] = ops.colsum((dh3_t if hd_p > 0 else dh3).view(M, Hd))
-            W1 = self.c(p + "feed_forward.intermediate_dense.weight", dtype)      # [I, Hd]
-            dx2 = ops.matmul_nn(du, W1, out_dtype=dtype, b_is_weight=True)
-            if tr:
-                grads[p + "feed_forward.intermediate_dense.weight"] = ops.matmul_tn(du, s["x2"].view(M, Hd))
-                grads[p + "feed_forward.intermediate_dense.bias"] = ops.colsum(du)
-            r = ops.layernorm_bwd(s["h2"], dx2.view(B, T, Hd), self.P(p + "final_layer_norm.weight").data, s["mu2"], s["rs2"], dres=dh3,
-                                  want_param_grads=tr, lp_copy=fuse_lp, lp_drop=(hd_p, seed, li * 8 + 0))   # consumer: this layer's attention-output dropout
-            dh2_lp = None
-            if fuse_lp:
-                r, dh2_lp = r[:-1], r[-1]
-                r = r if tr else r[0]
-            if tr:
-                dh2, grads[p + "final_layer_norm.weight"], grads[p + "final_layer_norm.bias"] = r
-            else:
-                dh2 = r
-            if tr and self.grad_ready is not None:                  # first bucket of the layer: the 6 feed-forward tensors (8.4 M of its 12.6 M
-                keys = [k for k in grads if k.startswith(p)]        # parameters) go out while the attention half of the backward runs
-                for k, v in zip(keys, self.grad_ready([grads[k] for k in keys])):
-                    grads[k] = v
-                n_sent = len(keys)
-            dh2_t = dh2_lp if dh2_lp is not None else ops.cast_dropout(dh2, dtype, (hd_p, seed, li * 8 + 0))
-            Wo = self.c(p + "attention.out_proj.weight", dtype)
-            dao = ops.matmul_nn(dh2_t.view(M, Hd), Wo, out_dtype=dtype, b_is_weight=True).view(B, T, nh, hd)
-            if tr:
-                grads[p + "attention.out_proj.weight"] = ops.matmul_tn(dh2_t.view(M, Hd), s["ao"].view(M, Hd))
-                grads[p + "attention.out_proj.bias"] = ops.colsum((dh2_t if hd_p > 0 else dh2).view(M, Hd))
-            qkv = s["qkv"]
-            dqkv = torch.empty_like(qkv)
-            ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dao, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx["klen"], scale,
-                              o=s["ao"], lse=s["lse"], drop=(at_p, seed, li * 8 + 3), drop_mask=s["amask"])
-            dx1 = ops.matmul_nn(dqkv.view(M, 3 * Hd), self.qkv_w(li, dtype), out_dtype=dtype, b_is_weight=True)
-            if tr:
-                dW = ops.matmul_tn(dqkv.view(M, 3 * Hd), s["x1"].view(M, Hd))
-                db = ops.colsum(dqkv.view(M, 3 * Hd))
+        if lp_ok:
+            r, dh_lp = r[:-1], r[-1]
+            r = r if tr else r[0]
+        if tr:
+            dh, gb = r
+            grads[ln1 + "_gb"] = gb
+        else:
+            dh = r
+        ctx["saved"][li] = None            # free as we go
+        st["dh"], st["dh_lp"] = dh, dh_lp
+
+    @staticmethod
+    def unpack_grads(grads: Dict[str, Tensor], Hd: int) -> Dict[str, Tensor]:
+        """Packed accumulators of _layer_backward -> HF parameter names (views, no copies)."""
+        out: Dict[str, Tensor] = {}
+        for k, v in grads.items():
+            if k.endswith("._qkv_w") or k.endswith("._qkv_b"):
+                base, kind = k[: -len("_qkv_w")], ("weight" if k.endswith("w") else "bias")
                 for j, n in enumerate(("q", "k", "v")):
-                    grads[p + f"attention.{n}_proj.weight"] = dW[j * Hd:(j + 1) * Hd]
-                    grads[p + f"attention.{n}_proj.bias"] = db[j * Hd:(j + 1) * Hd]
-            # the copy of dh serves the FFN-output dropout site of the layer below - unless that layer was dropped (LayerDrop: its site
-            # never ran, dh passes through to another site) or dmid is added to dh first (both only with dropout on)
-            lower = li - 1
-            lp_ok = fuse_lp and (hd_p == 0 or (lower >= ctx["first"] and not isinstance(ctx["saved"][lower], str)
-                                              and not (dmid_c is not None and 6 <= lower + 1 <= 9)))
-            r = ops.layernorm_bwd(s["h"], dx1.view(B, T, Hd), self.P(p + "layer_norm.weight").data, s["mu1"], s["rs1"], dres=dh2,
-                                  want_param_grads=tr, lp_copy=lp_ok, lp_drop=(hd_p, seed, lower * 8 + 2))
-            dh_lp = None
-            if lp_ok:
-                r, dh_lp = r[:-1], r[-1]
-                r = r if tr else r[0]
-            if tr:
-                dh, grads[p + "layer_norm.weight"], grads[p + "layer_norm.bias"] = r
+                    out[f"{base}{n}_proj.{kind}"] = v[j * Hd:(j + 1) * Hd]
+            elif k.endswith("._gb"):
+                base = k[: -len("_gb")]
+                out[base + "weight"], out[base + "bias"] = v[:Hd], v[Hd:]
             else:
-                dh = r
-            ctx["saved"][li] = None        # free as we go
-            if tr and self.grad_ready is not None:                  # second bucket: the layer's 10 attention / layer-norm tensors (dicts keep
-                keys = [k for k in grads if k.startswith(p)][n_sent:]   # insertion order: the first n_sent keys are already on their way)
-                for k, v in zip(keys, self.grad_ready([grads[k] for k in keys])):
-                    grads[k] = v
-        if self.grad_wait is not None:
-            self.grad_wait()
-        return grads
+                out[k] = v
+        return out
 
 
 class _EncodeFn(torch.autograd.Function):
-    """Autograd boundary: (wav, mask, trainable params...) -> (last, mid)."""
+    """Autograd boundary: (wav, masks of 1 or 2 passes, trainable params...) -> (last, mid) per pass.  Two passes = the reference's
+    audio_encoder(audio, mask1) / audio_encoder(audio, mask2) (model/trainer.py:94-95) as ONE node: their backward runs interleaved per layer."""
 
     @staticmethod
-    def forward(fctx, model: Wav2Vec2ModelHIP, wav, attention_mask, names, *params):
-        last, mid, ctx = model.encode(wav, attention_mask, save=True)
-        fctx.model, fctx.ctx, fctx.names = model, ctx, names
-        return last, mid
+    def forward(fctx, model: Wav2Vec2ModelHIP, wav, masks, names, *params):
+        outs, ctxs = [], []
+        for am in masks:
+            last, mid, ctx = model.encode(wav, am, save=True)
+            outs += [last, mid]
+            ctxs.append(ctx)
+        fctx.model, fctx.ctxs, fctx.names = model, ctxs, names
+        return tuple(outs)
 
     @staticmethod
-    def backward(fctx, dlast, dmid):
-        if fctx.ctx is None:
+    def backward(fctx, *douts):
+        live = [(c, douts[2 * i], douts[2 * i + 1]) for i, c in enumerate(fctx.ctxs) if c is not None]
+        if not live:
             return (None, None, None, None) + tuple(None for _ in fctx.names)
         if fctx.model.grad_pre is not None:
             fctx.model.grad_pre()
-        g = fctx.model.backward(fctx.ctx, dlast, dmid)
-        fctx.ctx = None
+        g = fctx.model.backward_multi([c for c, _, _ in live], [a for _, a, _ in live], [b for _, _, b in live])
+        g = fctx.model.unpack_grads(g, fctx.model.cfg["hidden_size"])
+        fctx.ctxs = None
         return (None, None, None, None) + tuple(g.get(n) for n in fctx.names)
 
 
-def w2v2_apply(model: Wav2Vec2ModelHIP, wav: Tensor, attention_mask: Optional[Tensor]):
+def w2v2_apply(model: Wav2Vec2ModelHIP, wav: Tensor, attention_mask, second_mask=None, two_passes: bool = False):
+    """One pass -> (last, mid); ``two_passes`` -> (last1, mid1, last2, mid2) for (attention_mask, second_mask)."""
+    masks = (attention_mask, second_mask) if two_passes else (attention_mask,)
     if getattr(model, "_np", None) is None:
         model._np = list(model.named_parameters())
     flags = tuple(p.requires_grad for _, p in model._np)
@@ -481,10 +541,13 @@ def w2v2_apply(model: Wav2Vec2ModelHIP, wav: Tensor, attention_mask: Optional[Te
             model._np_flags = flags
             model._np_train = ([n for (n, p), f in zip(model._np, flags) if f], [p for (n, p), f in zip(model._np, flags) if f])
         names, params = model._np_train
-        return _EncodeFn.apply(model, wav, attention_mask, names, *params)
+        return _EncodeFn.apply(model, wav, masks, names, *params)
+    outs = []
     with torch.no_grad():
-        last, mid, _ = model.encode(wav, attention_mask, save=False)
-    return last, mid
+        for am in masks:
+            last, mid, _ = model.encode(wav, am, save=False)
+            outs += [last, mid]
+    return tuple(outs)
 
 
 def load_local_config(path: str) -> dict:

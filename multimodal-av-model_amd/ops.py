@@ -282,9 +282,11 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, *, out_dtype: torch.dt
 
 
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
-                  want_param_grads: bool = False, lp_copy: bool = False, lp_drop: Optional[tuple] = None):
+                  want_param_grads: bool = False, lp_copy: bool = False, lp_drop: Optional[tuple] = None, gb_acc: Optional[Tensor] = None,
+                  packed_gb: bool = False):
     """dx (fp32) [, dgamma, dbeta]; with ``lp_copy`` the last element returned is a bf16 copy of dx written by the same kernel;
-    ``lp_drop`` = (p, seed, stream id) makes that copy dx o dropout-mask / (1 - p)."""
+    ``lp_drop`` = (p, seed, stream id) makes that copy dx o dropout-mask / (1 - p).  ``gb_acc`` (a [2 cols] tensor from an earlier call) /
+    ``packed_gb``: the parameter gradients come back as ONE packed tensor [dgamma | dbeta], accumulated into ``gb_acc`` when given."""
     cols = x.shape[-1]
     rows = x.numel() // cols
     assert x.is_contiguous() and dy.is_contiguous()
@@ -301,8 +303,14 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
                                          ptr(part), nblk, rows, cols, ptr(dxl), stream()), "av_layernorm_bwd")
     res = (dx,)
     if want_param_grads:
-        gb = colsum(part)
-        res = (dx, gb[:cols], gb[cols:])
+        if gb_acc is not None:
+            gb = colsum(part, out=gb_acc, accumulate=True)
+            res = (dx, gb)
+        elif packed_gb:
+            res = (dx, colsum(part))
+        else:
+            gb = colsum(part)
+            res = (dx, gb[:cols], gb[cols:])
     if lp_copy:
         return res + (dxl,)
     return res if want_param_grads else dx

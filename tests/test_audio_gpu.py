@@ -102,3 +102,40 @@ def test_two_passes_share_the_conv_feature_extractor():
         a3, _ = ae(wav, m1)
         assert len(calls) == 4
     assert torch.equal(a1, ref1) and torch.equal(a2, ref2) and torch.equal(a3, ref1)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_forward_pair_equals_two_calls(precision, tol):
+    """AudioEncoder.forward_pair (the reference's two audio passes as one autograd node, backward interleaved per layer with in-place
+    accumulation of the weight gradients) against two separate calls whose gradients autograd sums: same outputs bit for bit, same
+    parameter gradients up to the summation order."""
+    init = pkg("utils.init"); enc = pkg("model.encoder"); synth = pkg("dataset.synthetic")
+    pkg("precision").set_precision(precision)
+    cfg = init.W2V2_TINY
+    batch = synth.make_batch(3, 1.0, seed=8, ragged=True)
+    wav = batch["audio"].cuda()
+    m1 = (batch["mask1"] != 3).cuda()
+    m2 = m1.clone(); m2[0, 9000:] = False                          # a different padding pattern for the second pass
+    g = torch.Generator().manual_seed(4)
+    res = []
+    for pair in (True, False):
+        ae = enc.AudioEncoder(dict(cfg), freeze=True).cuda(); ae.load_state_dict(init.w2v2_state_dict(cfg)); ae.train()
+        for n, p in ae.model.named_parameters():
+            p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
+        if pair:
+            a1, mid1, a2, mid2 = ae.forward_pair(wav, m1, m2)
+        else:
+            a1, mid1 = ae(wav, m1); a2, mid2 = ae(wav, m2)
+        if not res:
+            ws = [torch.randn(a1.shape, generator=g).cuda() for _ in range(4)]
+        ((a1 * ws[0]).sum() + (mid1 * ws[1]).sum() + (a2 * ws[2]).sum() + (mid2 * ws[3]).sum()).backward()
+        res.append(((a1, mid1, a2, mid2), {n: p.grad.clone() for n, p in ae.model.named_parameters() if p.grad is not None}))
+    (o_p, g_p), (o_s, g_s) = res
+    for x, y in zip(o_p, o_s):
+        assert torch.equal(x, y)
+    assert sorted(g_p) == sorted(g_s) and len(g_p) == 4 * 16
+    for n in g_p:
+        if "k_proj.bias" in n:
+            continue
+        d = float((g_p[n] - g_s[n]).abs().max()); sc = float(g_s[n].abs().max())
+        assert d <= tol * sc + 1e-7, (n, d, sc)
