@@ -219,7 +219,7 @@ def main():
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt)
-        return dt, passes, float(out["total"])
+        return dt, passes, float(out["total"].detach())
 
     other = "deterministic" if args.variant == "as_executed" else "as_executed"
     dt, passes, loss = timed(args.variant)

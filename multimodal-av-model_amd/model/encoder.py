@@ -53,18 +53,21 @@ class AudioEncoder(nn.Module):
             for p in self.model.parameters():
                 p.requires_grad = False
 
-    def forward(self, x: torch.Tensor, attention_mask: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, valid_lengths=None):
+        """``valid_lengths`` (extension, optional): attention_mask.sum(-1) as host ints, when the caller has them (no device read-back)."""
         if not x.is_cuda:
             raise RuntimeError("AudioEncoder (HIP): input must be on the GPU; there is no CPU fallback")
-        return w2v2_apply(self.model, x, attention_mask)
+        return w2v2_apply(self.model, x, attention_mask, valid_lengths=None if valid_lengths is None else (valid_lengths,))
 
-    def forward_pair(self, x: torch.Tensor, attention_mask1: Optional[torch.Tensor], attention_mask2: Optional[torch.Tensor]):
+    def forward_pair(self, x: torch.Tensor, attention_mask1: Optional[torch.Tensor], attention_mask2: Optional[torch.Tensor],
+                     valid_lengths1=None, valid_lengths2=None):
         """The reference's two calls ``audio_encoder(audio, mask1)`` / ``audio_encoder(audio, mask2)`` (model/trainer.py:94-95) as one
         autograd node -> (last1, mid1, last2, mid2): same values, but the two backward passes run layer by layer with their weight
         gradients accumulated in place (one gradient bucket per layer and step under data parallelism)."""
         if not x.is_cuda:
             raise RuntimeError("AudioEncoder (HIP): input must be on the GPU; there is no CPU fallback")
-        return w2v2_apply(self.model, x, attention_mask1, attention_mask2, two_passes=True)
+        vl = None if valid_lengths1 is None or valid_lengths2 is None else (valid_lengths1, valid_lengths2)
+        return w2v2_apply(self.model, x, attention_mask1, attention_mask2, two_passes=True, valid_lengths=vl)
 
 
 # ---------------------------------------------------------------------------------------------------------------

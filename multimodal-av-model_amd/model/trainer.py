@@ -180,7 +180,8 @@ class MultimodalTrainer:
         tl = torch.cat([cpu_batch["text1_lengths"].cpu().long(), cpu_batch["text2_lengths"].cpu().long()])
         return {"_counts1": self._class_counts(cpu_batch["mask1"], T_enc), "_counts2": self._class_counts(cpu_batch["mask2"], T_enc),
                 "_ctc_input_lengths": il, "_ctc_target_lengths": tl,
-                "_same_padding": bool(torch.equal(cpu_batch["mask1"] != 3, cpu_batch["mask2"] != 3))}
+                "_same_padding": bool(torch.equal(cpu_batch["mask1"] != 3, cpu_batch["mask2"] != 3)),
+                "_audio_valid1": (cpu_batch["mask1"] != 3).sum(1).tolist(), "_audio_valid2": (cpu_batch["mask2"] != 3).sum(1).tolist()}
 
     def forward_losses(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """model/trainer.py:66-119 for one batch; everything stays on the device."""
@@ -214,10 +215,13 @@ class MultimodalTrainer:
         if passes == 2:
             self.audio_encoder.model._feat_cache = {}              # both passes read the same waveform: one conv feature-extractor run
         try:
+            v1, v2 = batch.get("_audio_valid1"), batch.get("_audio_valid2")      # host copies of the valid lengths (host_metadata)
+            if v1 is None and not batch["mask1"].is_cuda:                        # batch straight from a DataLoader: the masks ARE on the host
+                v1, v2 = (batch["mask1"] != 3).sum(1).tolist(), (batch["mask2"] != 3).sum(1).tolist()
             if passes == 2:
-                a1, mid1, a2, mid2 = self.audio_encoder.forward_pair(d["audio"], attn1, d["mask2"] != 3)
+                a1, mid1, a2, mid2 = self.audio_encoder.forward_pair(d["audio"], attn1, d["mask2"] != 3, v1, v2)
             else:
-                a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1)
+                a1, mid1 = self.audio_encoder(d["audio"], attention_mask=attn1, valid_lengths=v1)
                 a2, mid2 = a1, mid1
         finally:
             self.audio_encoder.model._feat_cache = None

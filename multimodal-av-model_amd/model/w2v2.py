@@ -218,8 +218,10 @@ class Wav2Vec2ModelHIP(nn.Module):
             Lin, cin = Lout, cs[i]
         return h
 
-    def encode(self, wav: Tensor, attention_mask: Optional[Tensor], save: bool):
-        """Returns (last fp32, mid fp32, ctx).  ctx holds what backward needs when ``save``."""
+    def encode(self, wav: Tensor, attention_mask: Optional[Tensor], save: bool, valid_lengths=None):
+        """Returns (last fp32, mid fp32, ctx).  ctx holds what backward needs when ``save``.  ``valid_lengths`` (optional host ints: number
+        of valid samples per item = attention_mask.sum(-1)) keeps the length law, the frame mask and SpecAugment's span count on the host:
+        no device index arithmetic (~25 tiny launches) and no device -> host read-back per pass."""
         cfg = self.cfg
         dtype = compute_dtype()
         dev = wav.device
@@ -249,7 +251,13 @@ class Wav2Vec2ModelHIP(nn.Module):
                 fc["src"], fc["dtype"], fc["feats"] = src, dtype, feats
         B, T, C = feats.shape
         klen = keep = None
-        if attention_mask is not None:
+        n_host = None
+        if attention_mask is not None and valid_lengths is not None:
+            import numpy as np
+            n_host = np.asarray([int(conv_out_lengths(cfg, int(v))) for v in valid_lengths], dtype=np.int64)
+            klen = ops.h2d_async(np.clip(n_host, 1, T).astype(np.int32), dev)
+            keep = ops.h2d_async((np.arange(T)[None, :] < n_host[:, None]).astype(np.uint8), dev)
+        elif attention_mask is not None:
             n = conv_out_lengths(cfg, attention_mask.long().sum(-1))
             klen = n.clamp(min=1, max=T).to(torch.int32)
             keep = (torch.arange(T, device=dev)[None, :] < n[:, None]).to(torch.uint8).contiguous()
@@ -260,14 +268,14 @@ class Wav2Vec2ModelHIP(nn.Module):
         if fp_p > 0:
             h = ops.cast_dropout(h, torch.float32, (fp_p, seed, S_FEATPROJ))             # hf:433
         if tm and sc["mask_time_prob"] > 0 and cfg.get("apply_spec_augment", True):      # hf:1272-1296 (host numpy RNG, as HF)
-            lengths = n.tolist() if attention_mask is not None else [T] * B
+            lengths = (n_host.tolist() if n_host is not None else n.tolist()) if attention_mask is not None else [T] * B
             sm = specaugment_mask(B, T, sc["mask_time_prob"], sc["mask_time_length"], lengths, sc["mask_time_min_masks"])
-            smt = torch.from_numpy(sm.astype("uint8")).to(dev)
+            smt = ops.h2d_async(sm.astype("uint8"), dev)
             L.check(L.lib().av_overwrite_rows(ops.ptr(h), ops.dt(h), ops.ptr(smt), ops.ptr(self.P("masked_spec_embed").data), B * T, Hd,
                                               ops.stream()), "av_overwrite_rows")
         if tm and sc["mask_feature_prob"] > 0 and cfg.get("apply_spec_augment", True):   # hf:1298-1316: drawn AFTER the time mask, same numpy RNG
             fmask = specaugment_mask(B, Hd, sc["mask_feature_prob"], sc["mask_feature_length"], [Hd] * B, sc["mask_feature_min_masks"])
-            fmt = torch.from_numpy(fmask.astype("uint8")).to(dev)
+            fmt = ops.h2d_async(fmask.astype("uint8"), dev)
             L.check(L.lib().av_zero_feature_cols(ops.ptr(h), ops.dt(h), ops.ptr(fmt), B, T, Hd, ops.stream()), "av_zero_feature_cols")
         if keep is not None:
             ops.mask_rows_(h, keep)                                                      # hf:752-755
@@ -507,10 +515,10 @@ class _EncodeFn(torch.autograd.Function):
     audio_encoder(audio, mask1) / audio_encoder(audio, mask2) (model/trainer.py:94-95) as ONE node: their backward runs interleaved per layer."""
 
     @staticmethod
-    def forward(fctx, model: Wav2Vec2ModelHIP, wav, masks, names, *params):
+    def forward(fctx, model: Wav2Vec2ModelHIP, wav, masks, valid, names, *params):
         outs, ctxs = [], []
-        for am in masks:
-            last, mid, ctx = model.encode(wav, am, save=True)
+        for am, vl in zip(masks, valid):
+            last, mid, ctx = model.encode(wav, am, save=True, valid_lengths=vl)
             outs += [last, mid]
             ctxs.append(ctx)
         fctx.model, fctx.ctxs, fctx.names = model, ctxs, names
@@ -520,18 +528,20 @@ class _EncodeFn(torch.autograd.Function):
     def backward(fctx, *douts):
         live = [(c, douts[2 * i], douts[2 * i + 1]) for i, c in enumerate(fctx.ctxs) if c is not None]
         if not live:
-            return (None, None, None, None) + tuple(None for _ in fctx.names)
+            return (None, None, None, None, None) + tuple(None for _ in fctx.names)
         if fctx.model.grad_pre is not None:
             fctx.model.grad_pre()
         g = fctx.model.backward_multi([c for c, _, _ in live], [a for _, a, _ in live], [b for _, _, b in live])
         g = fctx.model.unpack_grads(g, fctx.model.cfg["hidden_size"])
         fctx.ctxs = None
-        return (None, None, None, None) + tuple(g.get(n) for n in fctx.names)
+        return (None, None, None, None, None) + tuple(g.get(n) for n in fctx.names)
 
 
-def w2v2_apply(model: Wav2Vec2ModelHIP, wav: Tensor, attention_mask, second_mask=None, two_passes: bool = False):
-    """One pass -> (last, mid); ``two_passes`` -> (last1, mid1, last2, mid2) for (attention_mask, second_mask)."""
+def w2v2_apply(model: Wav2Vec2ModelHIP, wav: Tensor, attention_mask, second_mask=None, two_passes: bool = False, valid_lengths=None):
+    """One pass -> (last, mid); ``two_passes`` -> (last1, mid1, last2, mid2) for (attention_mask, second_mask).  ``valid_lengths``: optional
+    host-side sample counts per item, one list per pass (see Wav2Vec2ModelHIP.encode)."""
     masks = (attention_mask, second_mask) if two_passes else (attention_mask,)
+    valid = tuple(valid_lengths) if valid_lengths is not None else (None,) * len(masks)
     if getattr(model, "_np", None) is None:
         model._np = list(model.named_parameters())
     flags = tuple(p.requires_grad for _, p in model._np)
@@ -541,11 +551,11 @@ def w2v2_apply(model: Wav2Vec2ModelHIP, wav: Tensor, attention_mask, second_mask
             model._np_flags = flags
             model._np_train = ([n for (n, p), f in zip(model._np, flags) if f], [p for (n, p), f in zip(model._np, flags) if f])
         names, params = model._np_train
-        return _EncodeFn.apply(model, wav, masks, names, *params)
+        return _EncodeFn.apply(model, wav, masks, valid, names, *params)
     outs = []
     with torch.no_grad():
-        for am in masks:
-            last, mid, _ = model.encode(wav, am, save=False)
+        for am, vl in zip(masks, valid):
+            last, mid, _ = model.encode(wav, am, save=False, valid_lengths=vl)
             outs += [last, mid]
     return tuple(outs)
 

@@ -43,6 +43,12 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def h2d_async(arr, device) -> Tensor:
+    """numpy array -> device tensor without draining the stream: staged through the caching pinned-host allocator and copied with
+    non_blocking=True (a plain ``torch.tensor(host_data, device=cuda)`` synchronises the stream it runs on)."""
+    return torch.from_numpy(arr).pin_memory().to(device, non_blocking=True)
+
+
 def _req(t: Tensor, name: str):
     if not t.is_cuda:
         raise RuntimeError(f"{name}: tensor must live on the GPU (no CPU fallback in libavhip)")
