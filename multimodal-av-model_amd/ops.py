@@ -204,6 +204,9 @@ def _fast_ok(t: Tensor, K: int, N: int) -> bool:
 
 # k-major operands straight into the fast GEMM (transposed LDS reads) instead of a transpose pass; AVAMD_GEMM_KMAJOR=0 = old path
 KMAJOR = os.environ.get("AVAMD_GEMM_KMAJOR", "1") != "0"
+# dX of a weight that changes every step: 0 (default) = transpose the weight once per version (one 12 us pass, shared by both audio passes)
+# and run the row-major 8-phase kernel; 1 = feed the k-major weight to the 128 x 128 kernel (no transpose pass)
+KMAJOR_DX_HOT = os.environ.get("AVAMD_GEMM_KMAJOR_DX", "0") != "0"
 
 
 def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, act: int = L.ACT_NONE,
@@ -218,7 +221,7 @@ def matmul_nn(a: Tensor, b: Tensor, *, out_dtype: Optional[torch.dtype] = None, 
         out = torch.empty(a.shape[:-1] + (N,), dtype=out_dtype or a.dtype, device=a.device)
     kmajor_ok = KMAJOR and N % 8 == 0
     if _fast_ok(a, K, N) and K % 64 == 0 and (b_is_weight or not kmajor_ok):
-        bt = transpose_cached(b, hot_ok=kmajor_ok) if b_is_weight else transpose(b)   # [N, K]: K-contiguous operand for the fast kernel
+        bt = transpose_cached(b, hot_ok=kmajor_ok and KMAJOR_DX_HOT) if b_is_weight else transpose(b)   # [N, K]: K-contiguous operand for the fast kernel
         if bt is not None:
             gemm(a, bt, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act, aux=aux, R=R, alpha=alpha, drop=drop)
             return out

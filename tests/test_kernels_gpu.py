@@ -111,7 +111,9 @@ def test_batched_strided_gemm(dtype):
                                                       # ResNet layer3 / layer4 shapes on the 256 x 256 8-phase kernel (bf16, M >= 4096): ragged last
                                                       # row tile (M = 4500 / 4509), one and two column tiles, strided + 1x1 forms
                                                       (128, 256, 12, 2, 3, 125), (256, 256, 6, 1, 3, 125), (256, 512, 6, 2, 3, 501),
-                                                      (512, 512, 3, 1, 3, 501), (128, 256, 12, 2, 1, 125)])
+                                                      (512, 512, 3, 1, 3, 501), (128, 256, 12, 2, 1, 125),
+                                                      # ResNet layer2 shapes (N = 128) at M = 5760 / 5904: many row tiles, ragged last one
+                                                      (64, 128, 24, 2, 3, 40), (128, 128, 12, 1, 3, 41)])
 def test_conv2d_implicit_gemm(dtype, Cin, Cout, H, stride, k, N_):
     if dtype == torch.float32 and N_ > 5:
         pytest.skip("large shapes exercise the bf16 kernels")
