@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --same-device rehearses N>1 on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="build the process group and the gradient reducer even with one rank (RCCL path rehearsal)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the visual encoder on the main stream (no overlap)")
     ap.add_argument("--no-pair", action="store_true", help="one fusion/decoder call per speaker, as the reference does")
     args = ap.parse_args()
@@ -151,9 +152,11 @@ def main():
         os.environ.setdefault("AVAMD_LSTM_PERSISTENT", "0")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
@@ -173,7 +176,7 @@ def main():
         p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
     fu = fm.CrossAttentionFusion(512, cfg["hidden_size"], 512); fu.load_state_dict(init.fusion_state_dict(512, cfg["hidden_size"], 512))
     de = dm.CTCDecoder(1024, 800, 3); de.load_state_dict(init.decoder_state_dict(1024, 800))
-    reducer = dp.GradBucketReducer() if world > 1 else None
+    reducer = dp.GradBucketReducer(always_collective=args.force_dp) if (world > 1 or args.force_dp) else None
     t = tr.MultimodalTrainer(ve, ae, fu, de, tok.SyntheticTokenizer(800), learning_rate=1e-4, device=dev, lambda_=args.lambda_,
                              audio_passes=None, reducer=reducer, pair_batched=not args.no_pair,
                              visual_side_stream=not args.no_side_stream)
@@ -300,7 +303,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

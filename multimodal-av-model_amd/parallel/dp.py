@@ -16,9 +16,11 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, group=None, side_stream: bool = True):
+    def __init__(self, group=None, side_stream: bool = True, always_collective: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # issue the collectives even in a group of one rank (rehearsal of the RCCL path on a one-GPU box: same calls, same streams)
+        self.always = always_collective and dist.is_initialized()
         self.pending = []            # (work, flat, event)
         self.stream: Optional[torch.cuda.Stream] = None
         self._use_side = side_stream
@@ -39,7 +41,7 @@ class GradBucketReducer:
         for t in tensors:
             views.append(flat[off:off + t.numel()].view(t.shape))
             off += t.numel()
-        if self.world > 1:
+        if self.world > 1 or self.always:
             if flat.is_cuda and self._use_side:
                 s = self._side(flat.device)
                 s.wait_stream(torch.cuda.current_stream(flat.device))
