@@ -68,25 +68,31 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
-// bf16 perf path: Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7, far below bf16 resolution) with one exp + one rcp;
-// erf and the Gaussian density share the exponential
-__device__ __forceinline__ void erf_pdf_fast(float x, float& erfv, float& ex) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    ex = __expf(-z * z);                                   // = exp(-x^2/2)
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * ex;
-    erfv = x < 0.f ? -e : e;
+// bf16 perf path (GEMM epilogues; the matrix pipe idles while they run, so every VALU cycle counts): erf(z), z = |x| / sqrt(2), as the
+// odd polynomial z P(z^2) of degree 17 fitted on [0, 3] (|err| <= 2.8e-5, GELU abs err <= 5.8e-5, GELU' <= 1.4e-5: far below bf16
+// resolution), 1 beyond - 9 FMAs and no transcendental (the Abramowitz-Stegun form cost an exp and a reciprocal on top of 5 FMAs)
+__device__ __forceinline__ float erf_abs_poly(float z) {
+    const float z2 = z * z;
+    float p = 4.0719861260640755e-08f;
+    p = p * z2 + -1.9457509097264847e-06f;
+    p = p * z2 + 4.110950976610184e-05f;
+    p = p * z2 + -0.0005118074477650225f;
+    p = p * z2 + 0.004241328686475754f;
+    p = p * z2 + -0.025126988068223f;
+    p = p * z2 + 0.11113087832927704f;
+    p = p * z2 + -0.37536558508872986f;
+    p = p * z2 + 1.1282844543457031f;
+    return z >= 3.0f ? 1.0f : p * z;
 }
 __device__ __forceinline__ float gelu_fast(float x) {
-    float e, ex;
-    erf_pdf_fast(x, e, ex);
-    return 0.5f * x * (1.0f + e);
+    const float e = erf_abs_poly(fabsf(x) * 0.70710678118654752440f);
+    const float t = 0.5f * x;
+    return t + fabsf(t) * e;                               // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
 }
 __device__ __forceinline__ float gelu_grad_fast(float x) {
-    float e, ex;
-    erf_pdf_fast(x, e, ex);
-    return 0.5f * (1.0f + e) + x * 0.39894228040143267794f * ex;
+    const float e = erf_abs_poly(fabsf(x) * 0.70710678118654752440f);
+    const float cdf = 0.5f + (x < 0.f ? -0.5f : 0.5f) * e;
+    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
