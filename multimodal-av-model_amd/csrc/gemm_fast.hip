@@ -670,7 +670,7 @@ constexpr int V4_LDS = V4_EPI + 4096;                       // image (> the two 
 // a B half-tile per K-tile in a ring of four 32-KiB slots, refilled two phases after the last read (staggered groups, as above), the
 // DMA two K-tiles ahead, vmcnt(4) per phase.
 __device__ __forceinline__ void v4_quadrant_job(const av_gemm_args& p, const FastFlags& fl, char* smem, const bf16_t* A, const bf16_t* B,
-                                                const int m0, const int n0, const long long cbase, const float* R, const float* bias) {
+                                                const int m0, const int n0, const int m_end, const long long cbase, const float* R, const float* bias) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = __builtin_amdgcn_readfirstlane(w >> 2), wc = w & 3;
     const int r = lane & 15, g = lane >> 4;
@@ -750,7 +750,7 @@ __device__ __forceinline__ void v4_quadrant_job(const av_gemm_args& p, const Fas
         const int id = it * V4_NT + tid;
         const int row = id / CPR, cc = (id % CPR) * 8;
         const int gm = m0 + row, gn = n0 + cc;
-        if (gm >= p.M || gn >= p.N) continue;
+        if (gm >= m_end || gn >= p.N) continue;
         float v[8];
         const f32x4 v0 = *(const f32x4*)(cs + row * QLD + cc), v1 = *(const f32x4*)(cs + row * QLD + cc + 4);
 #pragma unroll
@@ -800,7 +800,7 @@ __device__ __forceinline__ void stage_conv2(const av_gemm_args& p, const ConvRow
 }
 
 template <bool CONV>
-__global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl, const int nfull) {
+__global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl, const int nfull, const int bm_eff) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
     const int wr = __builtin_amdgcn_readfirstlane(w >> 2), wc = w & 3;
@@ -826,7 +826,12 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     const int first_m = grp * GM;
     const int gsz = nbM - first_m < GM ? nbM - first_m : GM;
     const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
-    const int m0 = mb * V4_BM, n0 = nb * V4_BN;
+    // Row tiles are bm_eff <= 256 rows apart (a multiple of 16): the tile still stages 256 rows, but 16-row tiles beyond bm_eff (or beyond M) get
+    // neither fragment reads nor MFMAs nor stores.  The host picks bm_eff so that the tile count fills the 256 CUs (M = 64 x 199 tokens, N = 1024:
+    // 62 x 4 = 248 tiles of 208 rows instead of 50 x 4 = 200 of 256); the two wavefront groups alternate on a SIMD, so the skipped MFMAs
+    // of one group shorten the K-tile for both.
+    const int m0 = mb * bm_eff, n0 = nb * V4_BN;
+    const int rows_here = p.M - m0 < bm_eff ? p.M - m0 : bm_eff;
     const int z = blockIdx.z;
     const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
     const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
@@ -834,11 +839,14 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
     if (quad >= 0) {                                         // block-uniform
         const int qm = m0 + (quad >> 1) * 128, qn = n0 + (quad & 1) * 128;
-        if (qm < p.M && qn < p.N)
-            v4_quadrant_job(p, fl, smem, A, B, qm, qn, (long long)zo * p.oC + (long long)zi * p.sC, p.R ? p.R + (long long)zi * p.sR : nullptr,
-                            p.bias ? p.bias + (long long)zi * p.sBias : nullptr);
+        if (qm < m0 + rows_here && qn < p.N)
+            v4_quadrant_job(p, fl, smem, A, B, qm, qn, m0 + rows_here, (long long)zo * p.oC + (long long)zi * p.sC,
+                            p.R ? p.R + (long long)zi * p.sR : nullptr, p.bias ? p.bias + (long long)zi * p.sBias : nullptr);
         return;
     }
+    // 16-row tiles of mine that hold rows of this tile: A half h starts at row 128 h + 64 wr (wave-uniform counts in 0..4)
+    auto ntiles = [&](int start) { int n = (rows_here - start + 15) >> 4; return n < 0 ? 0 : (n > 4 ? 4 : n); };
+    const int nmt0 = __builtin_amdgcn_readfirstlane(ntiles(wr * 64)), nmt1 = __builtin_amdgcn_readfirstlane(ntiles(128 + wr * 64));
 
     f32x4 acc[2][2][4][2];                                   // [A half][B half][m-tile][n-tile]
 #pragma unroll
@@ -874,8 +882,8 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
     bf16x8 fa[4][2], fb[2][2];
 
-#define V4_READ_A(SLOT)                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+#define V4_READ_A(SLOT, NMT)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < (NMT)) {                                                 \
         fa[i][0] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + a_row + i * 2048 + ch0);                               \
         fa[i][1] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + a_row + i * 2048 + ch1); }
 #define V4_READ_B(SLOT)                                                                                            \
@@ -888,7 +896,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < ((QA) ? nmt1 : nmt0))                                \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
                 acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[QA][QB][i][j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         // phase 0: quadrant (A0, B0)
         V4_READ_B(3)
         __builtin_amdgcn_sched_barrier(0);
-        V4_READ_A(0)
+        V4_READ_A(0, nmt0)
         if (4 * t + 6 < nh) issue(t + 1, 2);
         V4_MMA(0, 0)
         // phase 1: (A0, B1)
@@ -909,7 +917,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         if (4 * t + 7 < nh) issue(t + 1, 3);
         V4_MMA(0, 1)
         // phase 2: (A1, B1)
-        V4_READ_A(2)
+        V4_READ_A(2, nmt1)
         if (4 * t + 8 < nh) issue(t + 2, 0);
         V4_MMA(1, 1)
         // phase 3: (A1, B0); the K-tile's one counted wait: all of K-tile t+1 has landed, the two youngest half-tiles (t+2) may fly
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
             const int id = it * V4_NT + tid;
             const int row = id / CPR, cc = (id % CPR) * 8;
             const int gm = m0 + half * 128 + row, gn = n0 + cc;
-            if (gm >= p.M || gn >= p.N) continue;
+            if (half * 128 + row >= rows_here || gn >= p.N) continue;
             float v[8];
             const f32x4 v0 = *(const f32x4*)(cs + row * V4_CLD + cc), v1 = *(const f32x4*)(cs + row * V4_CLD + cc + 4);
 #pragma unroll
@@ -1063,18 +1071,29 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
             v4c_attr = true;
         }
         const int nbM = av_cdiv(p.M, V4_BM), nbN = av_cdiv(p.N, V4_BN);
-        hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel<true>, dim3((unsigned)(nbM * nbN), 1, 1), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl, nbM * nbN);
+        hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel<true>, dim3((unsigned)(nbM * nbN), 1, 1), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl, nbM * nbN, V4_BM);
         AV_LAUNCH_CHECK();
         return AV_OK;
     }
     if (!conv && !narrow && v4_mode > 0 && p.M >= 256 && p.N >= 256) {
         const double nk = p.K / 64.0;
-        const long long t4 = (long long)av_cdiv(p.M, V4_BM) * av_cdiv(p.N, V4_BN) * p.batch;
+        const int nbN4 = av_cdiv(p.N, V4_BN);
+        static const int v4_tail = [] { const char* e = getenv("AVAMD_GEMM_V4_TAIL"); return e ? atoi(e) : 1; }();
+        static const int v4_bm = [] { const char* e = getenv("AVAMD_GEMM_V4_BM"); return e ? atoi(e) : 0; }();     // 0: choose; else force (multiple of 16)
+        // row-tile height: the tile time scales with the rows that get MFMAs (1.59 us per K-tile at 256 rows, measured; ~0.25 us of it does
+        // not scale), the count of tiles with their number; candidates keep whole 16-row tiles
+        int best_bm = V4_BM; double e4 = 1e30; int best_full = 0;
+        for (int bm = V4_BM; bm >= 160; bm -= 16) {
+            if (v4_bm && bm != v4_bm) continue;
+            const long long t4 = (long long)av_cdiv(p.M, bm) * nbN4 * p.batch;
+            const double per_tile = nk * (0.25 + 1.34 * bm / 256.0) + 5.0 * bm / 256.0;
+            const long long r4 = t4 % 256;
+            const bool tail = p.batch == 1 && v4_tail && t4 > 256 && r4 > 0 && r4 <= 128;
+            const double e = tail ? (double)(t4 / 256) * per_tile + (double)((4 * r4 + 255) / 256) * (nk * 0.45 + 3.0) : (double)((t4 + 255) / 256) * per_tile;
+            if (e < e4 * 0.98) { e4 = e; best_bm = bm; best_full = tail ? (int)(t4 - r4) : (int)t4; }
+        }
         const long long t2 = (long long)av_cdiv(p.M, V2_BM) * av_cdiv(p.N, V2_BN) * p.batch;
         const long long t1 = (long long)av_cdiv(p.M, BM) * av_cdiv(p.N, 128) * p.batch;
-        const long long r4 = t4 % 256;
-        const double e4 = (t4 > 256 && r4 > 0 && r4 <= 128 && p.batch == 1) ? (double)(t4 / 256) * (nk * 1.59 + 5.0) + (double)((4 * r4 + 255) / 256) * (nk * 0.45 + 3.0)
-                                                                             : (double)((t4 + 255) / 256) * (nk * 1.59 + 5.0);
         const double e2 = (double)((t2 + 255) / 256) * (nk * 0.85 + 2.0);
         const double e1 = (double)((t1 + 511) / 512) * (nk * 1.0 + 2.5);
         if (v4_mode >= 2 || e4 < (v2_ok ? (e2 < e1 ? e2 : e1) : e1)) {
@@ -1086,13 +1105,11 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
                 }
                 v4_attr = true;
             }
-            const int nbM = av_cdiv(p.M, V4_BM), nbN = av_cdiv(p.N, V4_BN);
-            const int ntile = nbM * nbN;
-            int nfull = ntile;
-            static const int v4_tail = [] { const char* e = getenv("AVAMD_GEMM_V4_TAIL"); return e ? atoi(e) : 1; }();
-            if (p.batch == 1 && v4_tail && ntile > 256 && ntile % 256 != 0 && ntile % 256 <= 128) nfull = ntile - ntile % 256;
+            const int nbM = av_cdiv(p.M, best_bm);
+            const int ntile = nbM * nbN4;
+            const int nfull = p.batch == 1 ? best_full : ntile;
             const unsigned nblocks = (unsigned)(nfull + 4 * (ntile - nfull));
-            hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel<false>, dim3(nblocks, 1, (unsigned)p.batch), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl, nfull);
+            hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel<false>, dim3(nblocks, 1, (unsigned)p.batch), dim3(V4_NT), V4_LDS, st, p, nbM, nbN4, fl, nfull, best_bm);
             AV_LAUNCH_CHECK();
             return AV_OK;
         }

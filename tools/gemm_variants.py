@@ -3,10 +3,10 @@
   python tools/gemm_variants.py            -> table;   child mode: python tools/gemm_variants.py --child"""
 import importlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(12736, 4096, 1024, "plain"), (12736, 4096, 1024, "bias"), (12736, 4096, 1024, "geluonly"), (12736, 4096, 1024, "c2only"),
-          (12736, 4096, 1024, "gelu+c2"), (12736, 4096, 1024, "gelu+c2+drop"), (12736, 4096, 1024, "plain+drop"), (12736, 4096, 1024, "gelugrad"),
-          (12736, 1024, 1024, "plain"), (12736, 1024, 1024, "res"), (12736, 1024, 1024, "res+drop")]
-VARIANTS = [("v4", {"AVAMD_GEMM_V4": "2"})]
+SHAPES = [(12736, 1024, 1024, "plain"), (12736, 1024, 1024, "res"), (12736, 1024, 4096, "plain"), (12736, 1024, 3072, "plain"),
+          (12736, 3072, 1024, "plain"), (12736, 4096, 1024, "plain"), (12736, 4096, 1024, "gelu+c2+drop"), (6368, 1024, 1024, "plain"),
+          (6368, 4096, 1024, "plain")]
+VARIANTS = [("BM=256", {"AVAMD_GEMM_V4_BM": "256"}), ("BM auto", {}), ("BM=208", {"AVAMD_GEMM_V4_BM": "208"})]
 
 
 def child():
