@@ -38,14 +38,17 @@ def _fwd_bwd(t, batch):
     return out, {k: (None if g is None else g.detach().clone()) for k, g in _grads(t).items()}
 
 
-@pytest.mark.parametrize("B,ragged", [(32, True), (64, False), (128, True)])
-def test_full_step_properties_at_config_sizes(B, ragged):
+@pytest.mark.parametrize("B,seconds,ragged", [(32, 4.0, True), (64, 4.0, False), (128, 4.0, True), (8, 15.0, True)])
+def test_full_step_properties_at_config_sizes(B, seconds, ragged):
+    """configs[1] (32 x 4 s), configs[3] / configs[4] per-GPU batches (64, 128 x 4 s) and configs[2] (8 x 15 s long form: T_enc 749 -> the
+    T > 256 attention kernels, 375 lip frames -> 375 BiLSTM steps and the unfused cross-attention path)."""
     init = pkg("utils.init"); synth = pkg("dataset.synthetic"); w2 = pkg("model.w2v2")
     cfg = init.W2V2_LARGE
     fx = np.load(os.path.join(GOLD, "c1.npz"))
-    cpu_batch = synth.make_batch(B, 4.0, seed=11, ragged=ragged)
-    assert cpu_batch["audio"].shape == (B, 64000) and cpu_batch["lip1"].shape[1] == 100
-    T_enc = int(w2.conv_out_lengths(cfg, 64000))
+    cpu_batch = synth.make_batch(B, seconds, seed=11, ragged=ragged)
+    n_audio = int(round(16000 * seconds))
+    assert cpu_batch["audio"].shape == (B, n_audio) and cpu_batch["lip1"].shape[1] == int(round(25 * seconds))
+    T_enc = int(w2.conv_out_lengths(cfg, n_audio))
     t = build(cfg, "bf16")
     batch = {k: v.cuda() for k, v in cpu_batch.items()}
     batch.update(t.host_metadata(cpu_batch, T_enc))
