@@ -102,7 +102,7 @@ def attention_report(records, steps):
     out = {}
     names = {"fwd64": "K7_w2v2_self_attention_fwd", "bwd64": "K7_w2v2_self_attention_bwd",
              "fwd128": "K17_fusion_cross_attention_fwd", "bwd128": "K17_fusion_cross_attention_bwd",
-             "blockfwd": "K17_fused_block_fwd", "blockbwd": "K17_fused_block_bwd"}
+             "blockfwd": "K17_fused_block_fwd", "blockbwd": "K17_attention_core_bwd"}
     for tag in sorted({r[2] for r in records}):
         rs = [r for r in records if r[2] == tag]
         ms = sum(r[0].elapsed_time(r[1]) for r in rs)

@@ -122,6 +122,10 @@ int av_dropout_uniform(float* u, long long n, unsigned long long seed, unsigned 
  * (what the backward reads).  embed_dim 512, 4 heads x 128, T <= 112 */
 int av_fusion_xattn_fwd(const void* a, const void* v, const void* w_in, const float* b_in, void* q_out, void* kv_out, void* o,
                         float* lse, int B, int T, int E, int H, float scale, void* stream);
+/* backward of that attention core (P recomputed from the row LSE): q, o, dout [B, T, 512], kv [B, T, 2, 512] bf16, lse [B, H, T] ->
+ * dq [B, T, 512], dkv [B, T, 2, 512]; one workgroup per (item, head), every operand staged once, no atomics (T <= 112) */
+int av_fusion_xattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv, int B, int T,
+                        int E, int H, float scale, void* stream);
 /* SpecAugment feature-axis masking (hf:1298-1316): x[b, t, c] = 0 for all t where mask[b * H + c] != 0 */
 int av_zero_feature_cols(void* x, int xdt, const unsigned char* mask, int B, int T, int H, void* stream);
 int av_overwrite_rows(void* x, int xdt, const unsigned char* mask, const float* embed, long long rows, int cols, void* stream);

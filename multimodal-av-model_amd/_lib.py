@@ -53,6 +53,7 @@ SIGNATURES = {
     "av_cast_dropout": [vp, i32, vp, i32, ll, f32, C.c_ulonglong, C.c_uint, vp],
     "av_dropout_uniform": [vp, ll, C.c_ulonglong, C.c_uint, vp],
     "av_fusion_xattn_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "av_fusion_xattn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "av_zero_feature_cols": [vp, i32, vp, i32, i32, i32, vp],
     "av_overwrite_rows": [vp, i32, vp, vp, ll, i32, vp],
     "av_axpby": [f32, vp, i32, f32, vp, ll, vp],

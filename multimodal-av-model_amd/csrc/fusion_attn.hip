@@ -263,6 +263,174 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd_kernel(const FxP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the attention core above (no masks, no dropout; T <= 112, head_dim 128): one workgroup per (item, head), every operand of
+// the sequence staged ONCE into LDS images (Q, K, V, dO: 128 KiB, 256-B rows, chunk swizzle sw256), delta = rowsum(dO o O) computed while
+// dO is staged.  Then, without any further barrier (the images are read-only):
+//   phase A - wavefront w owns 16 keys:    S = Q K^T and dP = dO V^T have the key on the lane and 4 queries in the registers = the B
+//             fragment of dV^T[d][key] += dO^T[d][32 q] P[32 q][key] and dK^T[d][key] += Q^T[d][32 q] dS[32 q][key]
+//             (dO^T, Q^T through ds_read_b64_tr_b16 from the row-major images);
+//   phase B - wavefront w owns 16 queries: S^T = K Q^T, dP^T = V dO^T put the query on the lane; dQ^T[d][q] += K^T[d][32 keys] dS^T.
+// P is recomputed from the saved row LSE.  No atomics, no cross-workgroup accumulation: bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BW_R = 128;                                    // image rows (frames padded to 128)
+constexpr int BW_IMG = BW_R * 256;                           // 32 KiB per image
+constexpr int BW_LDS = 4 * BW_IMG + 2 * BW_R * 4;            // Q, K, V, dO images + log2-LSE + delta
+
+struct FxB {
+    const bf16_t *q, *kv, *o, *dout;  // q, o, dout [B, T, E]; kv [B, T, 2, E]
+    const float* lse;                 // [B, H, T]
+    bf16_t *dq, *dkv;                 // dq [B, T, E], dkv [B, T, 2, E]
+    int B, T, H;
+    float scale;
+};
+
+__device__ __forceinline__ bf16x8 img_row(const char* img, int row, int ks, int g) {        // 8 consecutive d of row `row`: d = 32 ks + 8 g ..
+    return *(const bf16x8*)(img + row * 256 + (((4 * ks + g) ^ sw256(row)) << 4));
+}
+// A fragment [16 d = d-tile n][k = 32 rows r0 .. r0 + 31] of the transposed image, k-slot order of pack8 (rows r0 + 4 g + j, r0 + 16 + 4 g + j)
+__device__ __forceinline__ bf16x8 img_tr(const char* img, int r0, int n, int lane) {
+    const int row_lo = r0 + 4 * (lane >> 4) + ((lane >> 2) & 3), row_hi = row_lo + 16, pp = lane & 3, ch = 2 * n + (pp >> 1);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(img + row_lo * 256 + ((ch ^ sw256(row_lo)) << 4) + 8 * (pp & 1)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(img + row_hi * 256 + ((ch ^ sw256(row_hi)) << 4) + 8 * (pp & 1)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 pack8f(const f32x4& a, const f32x4& b) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (bf16_t)a[e]; v[4 + e] = (bf16_t)b[e]; }
+    return v;
+}
+
+__global__ __launch_bounds__(NT, 2) void fusion_xattn_bwd_kernel(const FxB p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem; char* Ks = smem + BW_IMG; char* Vs = smem + 2 * BW_IMG; char* Ds = smem + 3 * BW_IMG;
+    float* lse_s = (float*)(smem + 4 * BW_IMG);              // log2-domain LSE per query
+    float* del_s = lse_s + BW_R;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y, T = p.T;
+    const bf16_t* Q = p.q + (long long)b * T * E + h * HD;
+    const bf16_t* KV = p.kv + (long long)b * T * 2 * E + h * HD;
+    const bf16_t* O = p.o + (long long)b * T * E + h * HD;
+    const bf16_t* DO = p.dout + (long long)b * T * E + h * HD;
+    // ---- stage: 16-B chunks, 16 per row; rows >= T are zero.  delta needs O only here (8 lanes x 2 chunks cover a row: shuffle sum)
+    for (int c0 = tid; c0 < BW_R * 16; c0 += NT) {
+        const int row = c0 >> 4, ch = c0 & 15;
+        const bool ok = row < T;
+        const long long ro = (long long)(ok ? row : T - 1);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        const uint4 vq = *(const uint4*)(Q + ro * E + ch * 8), vk = *(const uint4*)(KV + ro * 2 * E + ch * 8);
+        const uint4 vv = *(const uint4*)(KV + ro * 2 * E + E + ch * 8), vd = *(const uint4*)(DO + ro * E + ch * 8), vo = *(const uint4*)(O + ro * E + ch * 8);
+        const int off = row * 256 + ((ch ^ sw256(row)) << 4);
+        *(uint4*)(Qs + off) = ok ? vq : z; *(uint4*)(Ks + off) = ok ? vk : z; *(uint4*)(Vs + off) = ok ? vv : z; *(uint4*)(Ds + off) = ok ? vd : z;
+        const bf16x8 d8 = __builtin_bit_cast(bf16x8, vd), o8 = __builtin_bit_cast(bf16x8, vo);
+        float sd = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sd += (float)d8[e] * (float)o8[e];
+        sd = ok ? sd : 0.f;
+        sd += __shfl_xor(sd, 1, 64); sd += __shfl_xor(sd, 2, 64); sd += __shfl_xor(sd, 4, 64); sd += __shfl_xor(sd, 8, 64);
+        if (ch == 0) del_s[row] = sd;
+    }
+    for (int i = tid; i < BW_R; i += NT) lse_s[i] = i < T ? p.lse[((long long)b * p.H + h) * T + i] * LOG2E : 0.f;
+    __syncthreads();
+
+    const float c = p.scale * LOG2E;
+    const int nt16 = (T + 15) >> 4;
+    if (w < nt16) {                                          // wave-uniform: EXEC stays all ones for the transposed reads
+        // ---- phase A: my 16 keys = tile w
+        {
+            const int krow = w * 16 + r;
+            bf16x8 kf[4], vf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { kf[ks] = img_row(Ks, krow, ks, g); vf[ks] = img_row(Vs, krow, ks, g); }
+            const bool kok = krow < T;
+            f32x4 dVt[8], dKt[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) { dVt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int qp = 0; qp < (T + 31) >> 5; ++qp) {
+                f32x4 Pt[2], St[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int q0 = 32 * qp + 16 * hf;
+                    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Qs, q0 + r, ks, g), kf[ks], s4, 0, 0, 0);     // S[query 4g+e][key r]
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Ds, q0 + r, ks, g), vf[ks], dp, 0, 0, 0);
+                    }
+                    const f32x4 l4 = *(const f32x4*)(lse_s + q0 + 4 * g), d4 = *(const f32x4*)(del_s + q0 + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pv = (kok && q0 + 4 * g + e < T) ? __builtin_amdgcn_exp2f(s4[e] * c - l4[e]) : 0.f;
+                        Pt[hf][e] = pv;
+                        St[hf][e] = pv * (dp[e] - d4[e]) * p.scale;
+                    }
+                }
+                const bf16x8 pf = pack8f(Pt[0], Pt[1]), sf = pack8f(St[0], St[1]);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    dVt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr(Ds, 32 * qp, n, lane), pf, dVt[n], 0, 0, 0);   // dV^T[d][key]
+                    dKt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr(Qs, 32 * qp, n, lane), sf, dKt[n], 0, 0, 0);   // dK^T[d][key]
+                }
+            }
+            if (krow < T) {
+                bf16_t* ok_ = p.dkv + ((long long)b * T + krow) * 2 * E + h * HD + 4 * g;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    bf16x4 a4, c4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a4[e] = (bf16_t)dKt[n][e]; c4[e] = (bf16_t)dVt[n][e]; }
+                    *(bf16x4*)(ok_ + 16 * n) = a4;
+                    *(bf16x4*)(ok_ + E + 16 * n) = c4;
+                }
+            }
+        }
+        // ---- phase B: my 16 queries = tile w
+        {
+            const int qrow = w * 16 + r;
+            bf16x8 qf[4], df[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { qf[ks] = img_row(Qs, qrow, ks, g); df[ks] = img_row(Ds, qrow, ks, g); }
+            const bool qok = qrow < T;
+            const float lq = lse_s[qrow], dq_ = del_s[qrow];
+            f32x4 dQt[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) dQt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tp = 0; tp < (T + 31) >> 5; ++tp) {
+                f32x4 St[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int k0 = 32 * tp + 16 * hf;
+                    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Ks, k0 + r, ks, g), qf[ks], s4, 0, 0, 0);     // S^T[key 4g+e][query r]
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Vs, k0 + r, ks, g), df[ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pv = (qok && k0 + 4 * g + e < T) ? __builtin_amdgcn_exp2f(s4[e] * c - lq) : 0.f;
+                        St[hf][e] = pv * (dp[e] - dq_) * p.scale;
+                    }
+                }
+                const bf16x8 sf = pack8f(St[0], St[1]);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) dQt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr(Ks, 32 * tp, n, lane), sf, dQt[n], 0, 0, 0);   // dQ^T[d][q]
+            }
+            if (qok) {
+                bf16_t* oq = p.dq + ((long long)b * T + qrow) * E + h * HD + 4 * g;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    bf16x4 a4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a4[e] = (bf16_t)dQt[n][e];
+                    *(bf16x4*)(oq + 16 * n) = a4;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int av_fusion_xattn_fwd(const void* a, const void* v, const void* w_in, const float* b_in, void* q_out, void* kv_out, void* o,
@@ -285,6 +453,28 @@ extern "C" int av_fusion_xattn_fwd(const void* a, const void* v, const void* w_i
     p.q = (bf16_t*)q_out; p.kv = (bf16_t*)kv_out; p.o = (bf16_t*)o; p.lse = lse;
     p.B = B; p.T = T; p.H = H; p.scale = scale;
     hipLaunchKernelGGL(fusion_xattn_fwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_fusion_xattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv, int B, int T,
+                                   int E_, int H, float scale, void* stream) {
+    AV_CHECK(q && kv && o && dout && lse && dq && dkv, "av_fusion_xattn_bwd: null pointer");
+    AV_CHECK(E_ == E && H * HD == E, "av_fusion_xattn_bwd: built for embed_dim 512 = 4 heads x 128 (got E=%d H=%d)", E_, H);
+    AV_CHECK(B > 0 && T > 0 && T <= TQ, "av_fusion_xattn_bwd: T=%d out of range (1..%d)", T, TQ);
+    AV_CHECK(((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dkv) % 16 == 0, "av_fusion_xattn_bwd: operands must be 16-byte aligned");
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)fusion_xattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS) != hipSuccess) {
+            av_set_error("av_fusion_xattn_bwd: cannot raise dynamic LDS to %d", BW_LDS);
+            return AV_ERR_LAUNCH;
+        }
+        attr = true;
+    }
+    FxB p;
+    p.q = (const bf16_t*)q; p.kv = (const bf16_t*)kv; p.o = (const bf16_t*)o; p.dout = (const bf16_t*)dout; p.lse = lse;
+    p.dq = (bf16_t*)dq; p.dkv = (bf16_t*)dkv; p.B = B; p.T = T; p.H = H; p.scale = scale;
+    hipLaunchKernelGGL(fusion_xattn_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(NT), BW_LDS, (hipStream_t)stream, p);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

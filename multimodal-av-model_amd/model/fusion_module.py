@@ -190,8 +190,11 @@ class _FusionFn(torch.autograd.Function):
         g["cross_attn_audio.out_proj.weight"] = ops.matmul_tn(da2v, s["o"].view(M, E)); g["cross_attn_audio.out_proj.bias"] = ops.colsum(da2v)
         do = ops.matmul_nn(da2v, c(mha.out_proj.weight)).view(B, Tv, nh, hd)
         q, kv = s["q"], s["kv"]
-        dq = torch.empty_like(q); dkv = torch.empty_like(kv)
-        ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], do, dq, dkv[:, :, 0], dkv[:, :, 1], None, hd ** -0.5, o=s["o"], lse=s["lse"])
+        if FUSED_XATTN and dtype == torch.bfloat16 and E == 512 and nh == 4 and Tv <= 112:
+            dq, dkv = ops.fusion_xattn_bwd(q, kv, s["o"], do.contiguous(), s["lse"], hd ** -0.5)
+        else:
+            dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+            ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], do, dq, dkv[:, :, 0], dkv[:, :, 1], None, hd ** -0.5, o=s["o"], lse=s["lse"])
         Win = c(mha.in_proj_weight)
         dq2, dkv2 = dq.view(M, E), dkv.view(M, 2 * E)
         dWin = torch.empty((3 * E, E), dtype=torch.float32, device=dout.device)

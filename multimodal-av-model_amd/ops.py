@@ -442,6 +442,19 @@ def fusion_xattn_fwd(a: Tensor, v: Tensor, w_in: Tensor, b_in: Tensor, nh: int, 
     return o, q, kv, lse
 
 
+def fusion_xattn_bwd(q: Tensor, kv: Tensor, o: Tensor, do: Tensor, lse: Tensor, scale: float):
+    """Backward of the fused cross-attention core (csrc/fusion_attn.hip): q, o, do [B,T,nh,hd], kv [B,T,2,nh,hd] bf16 -> (dq, dkv)."""
+    B, T, nh, hd = q.shape
+    E = nh * hd
+    assert q.is_contiguous() and kv.is_contiguous() and o.is_contiguous() and do.is_contiguous()
+    dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+    es = q.element_size()
+    _probed("blockbwd", 10.0 * B * T * T * E, es * B * T * E * 8,
+            lambda: L.check(L.lib().av_fusion_xattn_bwd(ptr(q), ptr(kv), ptr(o), ptr(do), ptr(lse), ptr(dq), ptr(dkv), B, T, E, nh, scale, stream()),
+                            "av_fusion_xattn_bwd"))
+    return dq, dkv
+
+
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: Tensor, dv: Tensor, klen: Optional[Tensor],
                   scale: float, o: Optional[Tensor] = None, lse: Optional[Tensor] = None, drop: Optional[tuple] = None,
                   drop_mask: Optional[Tensor] = None) -> None:

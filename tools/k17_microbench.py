@@ -32,3 +32,13 @@ for name, fn in (("fused block (save q/kv/lse)", lambda: ops.fusion_xattn_fwd(a,
                  ("3 launches: q GEMM + kv GEMM + attention", unfused)):
     us = timeit(fn)
     print(f"B={B} T={T}: {name:42s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s = {fl / us / 1e6 / 2500:.3f} of the bf16 MFMA peak", flush=True)
+
+q = torch.randn(B, T, nh, hd, device="cuda").to(torch.bfloat16); kv = torch.randn(B, T, 2, nh, hd, device="cuda").to(torch.bfloat16)
+do = torch.randn(B, T, nh, hd, device="cuda").to(torch.bfloat16)
+o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], None, hd ** -0.5, need_lse=True)
+dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+flb = 10.0 * B * T * T * E
+for name, fn in (("whole-sequence core backward", lambda: ops.fusion_xattn_bwd(q, kv, o, do, lse, hd ** -0.5)),
+                 ("tiled backward kernels (delta + kv + q)", lambda: ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], do, dq, dkv[:, :, 0], dkv[:, :, 1], None, hd ** -0.5, o=o, lse=lse))):
+    us = timeit(fn)
+    print(f"B={B} T={T}: {name:42s} {us:8.1f} us  {flb / us / 1e6:7.1f} TF/s = {flb / us / 1e6 / 2500:.3f} of the bf16 MFMA peak", flush=True)
