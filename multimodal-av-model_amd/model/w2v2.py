@@ -29,6 +29,8 @@ from ..utils.shadow import ParamCache
 Tensor = torch.Tensor
 # attention-dropout keep bits evaluated once per step on a side stream (0: every kernel generates its masks itself; A/B runs)
 DROP_BITS = os.environ.get("AVAMD_ATTN_DROPBITS", "1") != "0"
+# the second audio pass of a step runs on its own stream beside the first (HBM-bound row kernels of one pass overlap MFMA-bound GEMMs of the other)
+PASS_STREAMS = os.environ.get("AVAMD_PASS_STREAMS", "1") != "0"
 
 
 def param_shapes(cfg: dict) -> Dict[str, tuple]:
@@ -249,6 +251,8 @@ class Wav2Vec2ModelHIP(nn.Module):
             feats = self.features(wav, dtype)
             if fc is not None:
                 fc["src"], fc["dtype"], fc["feats"] = src, dtype, feats
+                if feats.is_cuda:                                # a pass on another stream waits for exactly this point
+                    fc["evt"] = torch.cuda.Event(); fc["evt"].record()
         B, T, C = feats.shape
         klen = keep = None
         n_host = None
@@ -510,6 +514,19 @@ class Wav2Vec2ModelHIP(nn.Module):
         return out
 
 
+def _tensors_of(obj):
+    """All CUDA tensors inside nested tuples / lists / dicts."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
+
+
 class _EncodeFn(torch.autograd.Function):
     """Autograd boundary: (wav, masks of 1 or 2 passes, trainable params...) -> (last, mid) per pass.  Two passes = the reference's
     audio_encoder(audio, mask1) / audio_encoder(audio, mask2) (model/trainer.py:94-95) as ONE node: their backward runs interleaved per layer."""
@@ -517,10 +534,39 @@ class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(fctx, model: Wav2Vec2ModelHIP, wav, masks, valid, names, *params):
         outs, ctxs = [], []
-        for am, vl in zip(masks, valid):
-            last, mid, ctx = model.encode(wav, am, save=True, valid_lengths=vl)
+        fc = getattr(model, "_feat_cache", None)
+        own_cache = len(masks) == 2 and fc is None           # both passes read the same waveform: one conv feature-extractor run
+        if own_cache:
+            model._feat_cache = fc = {}
+        two_streams = PASS_STREAMS and len(masks) == 2 and wav.is_cuda
+        if two_streams:
+            dev = wav.device
+            main = torch.cuda.current_stream(dev)
+            if getattr(model, "_pass_stream", None) is None:
+                model._pass_stream = torch.cuda.Stream(device=dev)
+            side = model._pass_stream
+            start = torch.cuda.Event(); start.record(main)           # everything enqueued before this forward (weights of the last Adam step ...)
+        for i, (am, vl) in enumerate(zip(masks, valid)):
+            if two_streams and i == 1:
+                # pass 2 on its own stream: it needs the shared conv features of pass 1 (event recorded right behind them), nothing else of it
+                side.wait_event(start)
+                if fc.get("evt") is not None:
+                    side.wait_event(fc["evt"])
+                with torch.cuda.stream(side):
+                    last, mid, ctx = model.encode(wav, am, save=True, valid_lengths=vl)
+                main.wait_stream(side)
+                # allocator bookkeeping: blocks of the side pool that the main stream reads later (outputs, everything saved for the backward),
+                # and main-pool blocks the side stream read
+                for t in _tensors_of((last, mid, ctx)):
+                    t.record_stream(main)
+                for t in _tensors_of((wav, am, fc.get("feats"))):
+                    t.record_stream(side)
+            else:
+                last, mid, ctx = model.encode(wav, am, save=True, valid_lengths=vl)
             outs += [last, mid]
             ctxs.append(ctx)
+        if own_cache:
+            model._feat_cache = None
         fctx.model, fctx.ctxs, fctx.names = model, ctxs, names
         return tuple(outs)
 
