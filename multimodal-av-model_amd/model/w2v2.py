@@ -386,16 +386,45 @@ class Wav2Vec2ModelHIP(nn.Module):
             # dh_lp: bf16 copy of dh (with the hidden-dropout mask of the consuming site folded in) when it is current
             states.append(dict(dh=dh, dh_lp=None, dmid=dmid.contiguous().float() if dmid is not None else None))
         first = min(c["first"] for c in ctxs)
+        dev = ctxs[0]["hL"].device
+        # Two passes: the second one walks the layers on its own stream, ONE LAYER BEHIND the first (its weight-gradient products accumulate
+        # into the buffers the first pass creates for that layer), so that the HBM-bound row kernels of one pass overlap the GEMMs of the other
+        two_streams = PASS_STREAMS and len(ctxs) == 2 and dev.type == "cuda"
+        if two_streams:
+            main = torch.cuda.current_stream(dev)
+            if getattr(self, "_pass_stream", None) is None:
+                self._pass_stream = torch.cuda.Stream(device=dev)
+            side = self._pass_stream
+            side.wait_stream(main)                                  # d(last) / d(mid) of pass 2 and its final-LayerNorm backward were enqueued on main
+            for t in _tensors_of(states[1]):
+                t.record_stream(side)
         for li in range(nl - 1, first - 1, -1):
             p = f"encoder.layers.{li}."
-            for ctx, st in zip(ctxs, states):
-                if li >= ctx["first"]:
+            for i, (ctx, st) in enumerate(zip(ctxs, states)):
+                if li < ctx["first"]:
+                    continue
+                if two_streams and i == 1:
+                    done0 = torch.cuda.Event(); done0.record(main)   # pass 1 has written this layer's gradient buffers
+                    side.wait_event(done0)
+                    with torch.cuda.stream(side):
+                        before = set(grads)
+                        self._layer_backward(ctx, st, li, grads)
+                    for k in grads:                                 # allocator bookkeeping across the two streams
+                        if k.startswith(p):
+                            grads[k].record_stream(side if k in before else main)
+                else:
                     self._layer_backward(ctx, st, li, grads)
             if self.grad_ready is not None:                         # the layer's gradients (all passes) go out while the next layer's backward runs
+                if two_streams:
+                    main.wait_stream(side)
                 keys = [k for k in grads if k.startswith(p)]
                 if keys:
                     for k, v in zip(keys, self.grad_ready([grads[k] for k in keys])):
                         grads[k] = v
+        if two_streams:
+            main.wait_stream(side)
+            for t in _tensors_of(states[1]):
+                t.record_stream(main)
         if self.grad_wait is not None:
             self.grad_wait()
         return grads
