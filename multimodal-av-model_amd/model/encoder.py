@@ -169,13 +169,29 @@ class VisualEncoder(nn.Module):
         dev = bn.weight.device
         scale = torch.empty(C, dtype=torch.float32, device=dev); shift = torch.empty(C, dtype=torch.float32, device=dev)
         ws = None
-        if training:                                          # one zeroed workspace per encoder: the finalize kernel leaves it zeroed
-            if self._bn_ws is None or self._bn_ws.device != dev:
-                self._bn_ws = torch.zeros(2 * 1024, dtype=torch.float64, device=dev)
-            ws = self._bn_ws
+        if training:                                          # one zeroed workspace per encoder AND stream: the finalize kernel leaves it zeroed
+            sid = ops.stream()
+            if self._bn_ws is None or not isinstance(self._bn_ws, dict):
+                self._bn_ws = {}
+            ws = self._bn_ws.get(sid)
+            if ws is None or ws.device != dev:
+                ws = self._bn_ws[sid] = torch.zeros(2 * 1024, dtype=torch.float64, device=dev)
+            # two forward calls of one step on two streams (the trainer's two lip streams): the running statistics must be updated in call
+            # order (model/trainer.py:88-89: lip1, then lip2), BatchNorm by BatchNorm - the leading call records an event behind each of
+            # its finalize kernels, the following call waits for it
+            sync = getattr(self, "_bn_sync", None)
+            if sync is not None:
+                mode, evs = sync
+                i = self._bn_idx
+                self._bn_idx += 1
+                if mode == "follow" and i < len(evs):
+                    torch.cuda.current_stream(dev).wait_event(evs[i])
         L.check(L.lib().av_bn_finalize(ops.ptr(stats), nblk, count, ops.ptr(bn.weight.data), ops.ptr(bn.bias.data),
                                        ops.ptr(bn.running_mean), ops.ptr(bn.running_var), float(bn.momentum), float(bn.eps),
                                        int(training), ops.ptr(scale), ops.ptr(shift), C, ops.ptr(ws), 1, ops.stream()), "av_bn_finalize")
+        if training and getattr(self, "_bn_sync", None) is not None and self._bn_sync[0] == "lead":
+            ev = torch.cuda.Event(); ev.record()
+            self._bn_sync[1].append(ev)
         if training:
             self._nbt.append(bn.num_batches_tracked)        # bumped once per forward with one multi-tensor add (27 tiny launches otherwise)
         return scale, shift
@@ -220,8 +236,10 @@ class VisualEncoder(nn.Module):
     @torch.no_grad()
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
         self._nbt = []
-        if self._bn_ws is not None:
-            self._bn_ws.zero_()                                  # one clear per forward (robust against an aborted previous forward)
+        if isinstance(self._bn_ws, dict) and x.is_cuda:
+            ws = self._bn_ws.get(ops.stream())
+            if ws is not None:
+                ws.zero_()                                       # one clear per forward (robust against an aborted previous forward)
         dtype = compute_dtype()
         training = self.training            # .train() on the frozen encoder => batch statistics + running-stat update
         B, C, T, H, W = x.shape

@@ -44,6 +44,7 @@ def word_error_rate(refs, hyps) -> float:
 
 
 _FUSED_LOSS = os.environ.get("AVAMD_FUSED_LOSS", "1") != "0"
+_VIS_STREAMS = int(os.environ.get("AVAMD_VISUAL_STREAMS", "2"))          # 1: both speakers' lip streams on one side stream
 
 
 class _CombineFn(torch.autograd.Function):
@@ -188,13 +189,28 @@ class MultimodalTrainer:
         d = self._to_dev(batch)
         use_side = self.visual_side_stream and d["audio"].is_cuda
         if use_side:
+            # the frozen visual encoder runs beside the wav2vec2 forward, one stream per speaker: its HBM-bound BatchNorm / pooling passes overlap
+            # the other streams' MFMA-bound kernels
+            dev_ = d["audio"].device
             if self._vstream is None:
-                self._vstream = torch.cuda.Stream(device=d["audio"].device)
-            main = torch.cuda.current_stream(d["audio"].device)
+                self._vstream = torch.cuda.Stream(device=dev_)
+                self._vstream2 = torch.cuda.Stream(device=dev_) if _VIS_STREAMS >= 2 else self._vstream
+            main = torch.cuda.current_stream(dev_)
+            two = self._vstream2 is not self._vstream
+            evs = []
             self._vstream.wait_stream(main)
             with torch.cuda.stream(self._vstream):
+                if two:
+                    self.visual_encoder._bn_sync, self.visual_encoder._bn_idx = ("lead", evs), 0
                 vf1 = self.visual_encoder(d["lip1"])
-                vf2 = self.visual_encoder(d["lip2"])
+            if two:
+                self._vstream2.wait_stream(main)
+                self.visual_encoder._bn_sync, self.visual_encoder._bn_idx = ("follow", evs), 0
+            try:
+                with torch.cuda.stream(self._vstream2):
+                    vf2 = self.visual_encoder(d["lip2"])
+            finally:
+                self.visual_encoder._bn_sync = None
         else:
             vf1 = self.visual_encoder(d["lip1"])
             vf2 = self.visual_encoder(d["lip2"])
@@ -243,6 +259,8 @@ class MultimodalTrainer:
             c1 = c2 = torch.zeros((), device=a1.device)
         if use_side:
             main.wait_stream(self._vstream)
+            if self._vstream2 is not self._vstream:
+                main.wait_stream(self._vstream2)
             vf1.record_stream(main); vf2.record_stream(main)
         B = a1.shape[0]
         if self.pair_batched:
