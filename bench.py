@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --same-device rehearses N>1 on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--force-dp", action="store_true", help="build the process group and the gradient reducer even with one rank (RCCL path rehearsal)")
-    ap.add_argument("--no-side-stream", action="store_true", help="run the visual encoder on the main stream (no overlap)")
+    ap.add_argument("--no-side-stream", action="store_true", help="one stream: visual encoder and second audio pass on the main stream (no overlap; profiling)")
     ap.add_argument("--no-pair", action="store_true", help="one fusion/decoder call per speaker, as the reference does")
     args = ap.parse_args()
 
@@ -180,6 +180,8 @@ def main():
     t = tr.MultimodalTrainer(ve, ae, fu, de, tok.SyntheticTokenizer(800), learning_rate=1e-4, device=dev, lambda_=args.lambda_,
                              audio_passes=None, reducer=reducer, pair_batched=not args.no_pair,
                              visual_side_stream=not args.no_side_stream)
+    if args.no_side_stream:
+        imp("model.w2v2").PASS_STREAMS = False
     t.fixed_projection = init.projection_params(cfg["hidden_size"])      # identical on every rank (SURVEY §8e caveat 4)
     t.visual_encoder.train(); t.audio_encoder.train(); t.fusion_module.train(); t.decoder1.train()
 
@@ -229,11 +231,13 @@ def main():
     second = None if args.single_variant else timed(other)
     set_variant(args.variant)
     # roofline leg: the SAME workload for a few more steps with per-launch events around the dominant kernel and the attention
-    # launches.  The side stream is switched off here so that the events bracket only the kernel (with two streams the elapsed time
-    # between events includes waiting for the other stream's kernels); this is what rocprofv3 reports as duration.
+    # launches.  The side streams (visual encoder, second audio pass) are switched off here so that the events bracket only the kernel
+    # (with several streams the elapsed time between events includes the other streams' kernels); this is what rocprofv3 reports as
+    # the duration of a kernel that runs alone.
     probe = attn = None
     if not args.no_probe and rank == 0 and world == 1:
         t.visual_side_stream = False
+        imp("model.w2v2").PASS_STREAMS = False                 # probe leg: one stream, so that the events bracket exactly one kernel
         t.train_step(batch)
         torch.cuda.synchronize()
         ops.GemmProbe.start(L.AV_BF16 if args.precision == "bf16" else L.AV_F32, L.A_ROWMAJOR, L.B_NK, True)
