@@ -248,6 +248,15 @@ def main():
         torch.cuda.synchronize()
         probe = ops.GemmProbe.stop()
         probe["steps"] = probe_steps
+        if os.environ.get("AVAMD_PROBE_SHAPES"):                # per-shape table of the probed family (tools / DESIGN only)
+            agg = {}
+            for r in probe["records"]:
+                a = agg.setdefault(r[4], [0, 0.0, 0.0])
+                a[0] += 1; a[1] += r[0].elapsed_time(r[1]); a[2] += r[2]
+            with open(os.environ["AVAMD_PROBE_SHAPES"], "w") as f:
+                f.write("M N K batch act bias R aux C2 drop conv stats | launches/step  us/launch  TF/s  ms/step\n")
+                for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    f.write(" ".join(str(int(x)) for x in k) + f" | {a[0] / probe_steps:6.1f} {1000 * a[1] / a[0]:8.1f} {a[2] / a[1] / 1e9:7.1f} {a[1] / probe_steps:7.2f}\n")
         attn = attention_report(ops.AttnProbe.stop(), probe_steps)
 
     if rank == 0:

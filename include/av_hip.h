@@ -35,6 +35,9 @@ extern "C" {
 #define AV_ACT_NONE 0
 #define AV_ACT_GELU 1          /* v = gelu(v)                     hf:565-572, hf:291-299 */
 #define AV_ACT_MUL_GELU_GRAD 2 /* v = v * gelu'(aux[m][n])        backward of the above  */
+#define AV_ACT_GELU_GF 3       /* m = dropout multiplier; C2 = gelu'(v) * m (the "gradient factor"), v = gelu(v) * m: the
+                                  backward of this activation + dropout site is then ONE multiply, AV_ACT_MUL_AUX        */
+#define AV_ACT_MUL_AUX 4       /* v = v * aux[m][n]               backward of AV_ACT_GELU_GF (aux = its C2)              */
 
 const char* av_last_error(void);
 int av_version(void);
@@ -54,7 +57,7 @@ typedef struct av_gemm_args {
     void* C2;          /* optional, same dtype/ld as C */
     const float* bias; /* optional [N] */
     const float* R;    /* optional fp32 residual, ld = ldr */
-    const void* aux;   /* AV_ACT_MUL_GELU_GRAD operand, dtype = aux_dtype, ld = ldc */
+    const void* aux;   /* AV_ACT_MUL_GELU_GRAD / AV_ACT_MUL_AUX operand, dtype = aux_dtype, ld = ldc */
     float* stats;      /* optional [ceil(M/128)][2][N] fp32 partials (batch must be 1) */
     int M, N, K, batch;
     long long lda, ldb, ldc, ldr;

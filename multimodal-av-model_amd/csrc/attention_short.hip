@@ -203,6 +203,140 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short_kernel(const AttnP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- forward, one exposed round trip
+// Same arithmetic as attn_fwd_short_kernel; what changes is WHEN memory is touched.  The kernel above pays four serial global round
+// trips per workgroup before its first MFMA (K image, V image - each through registers, the LDS store waits for the loads - then the
+// Q fragments of the first and of the second query tile inside the tile loop) and was latency-bound (42 us at 64 x 16 x 199: 2.1 TB/s of
+// algorithmic traffic, 8.6 % MFMA).  Here every byte the workgroup needs is requested in the first ~20 instructions: the K and V images
+// by LDS-DMA (global_load_lds_dwordx4: one wavefront instruction fills 8 swizzled 128-B rows, source chunk = LDS chunk ^ (row & 7), no
+// registers), the Q fragments of BOTH query tiles of the wavefront into registers; one vmcnt(0) + one barrier, then pure LDS / MFMA work.
+// Rows beyond Tk are clamped to the last row instead of zero-filled: their scores are masked to -inf (P = 0 exactly) and V is finite.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// image rows [8 grp, 8 grp + 8) <- src rows clamped to nvalid - 1 (one instruction per wavefront; grp must be wave-uniform)
+__device__ __forceinline__ void dma_rows8(bf16_t* img, const bf16_t* __restrict__ src, long long rs, int nvalid, int grp, int lane) {
+    const int sub = lane >> 3, pch = lane & 7;
+    int row = grp * 8 + sub;
+    row = row < nvalid ? row : nvalid - 1;
+    const bf16_t* s = src + (long long)row * rs + ((pch ^ sub) << 3);
+    __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)((char*)img + grp * 1024), 16, 0, 0);
+}
+
+template <int NKP, int DROP>
+__global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = (bf16_t*)smem;
+    bf16_t* Vs = Ks + NKP * 32 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    int klen = p.klen ? p.klen[b] : p.Tk;
+    if (klen > p.Tk) klen = p.Tk;
+    if (klen < 1) klen = 1;
+    const bf16_t* Q = (const bf16_t*)p.q + (long long)b * p.q_bs + (long long)h * 64;
+    const bf16_t* K = (const bf16_t*)p.k + (long long)b * p.k_bs + (long long)h * 64;
+    const bf16_t* V = (const bf16_t*)p.v + (long long)b * p.v_bs + (long long)h * 64;
+    constexpr int NG = NKP * 4;                                 // 8-row groups per image
+    for (int i = w; i < 2 * NG; i += NW) {                      // wave-uniform
+        if (i < NG) dma_rows8(Ks, K, p.k_rs, p.Tk, i, lane);
+        else dma_rows8(Vs, V, p.v_rs, p.Tk, i - NG, lane);
+    }
+    const int nqt = (p.Tq + 15) >> 4;                           // <= 16: at most two query tiles per wavefront
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int qrow = (w + NW * i) * 16 + r;
+        const bf16_t* qp = Q + (long long)(qrow < p.Tq ? qrow : p.Tq - 1) * p.q_rs + 8 * g;
+        qf[i][0] = *(const bf16x8*)qp; qf[i][1] = *(const bf16x8*)(qp + 32);
+    }
+    uint2 mb[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    if constexpr (DROP == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qt = (w + NW * i) < nqt ? (w + NW * i) : nqt - 1;
+            mb[i] = ((const uint2*)p.dmask)[((((long long)b * p.H + h) * nqt + qt) << 6) + lane];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float c = p.scale * LOG2E;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int qt = w + NW * i;
+        if (qt >= nqt) break;                                   // wave-uniform
+        asm volatile("" ::: "memory");                          // keep the LDS fragment reads of the two tiles apart (no cross-tile hoisting: spills)
+        const int qrow = qt * 16 + r;
+        f32x4 S[2 * NKP];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; ++t) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            a = mfma(row_frag(Ks, 16 * t + r, g), qf[i][0], a);
+            a = mfma(row_frag(Ks, 16 * t + r, 4 + g), qf[i][1], a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = (16 * t + 4 * g + e) < klen ? a[e] * c : -INFINITY;
+                mx = fmaxf(mx, a[e]);
+            }
+            S[t] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(S[t][e] - mx);
+                sum += pv;
+                S[t][e] = pv;
+            }
+        if (DROP) {
+            const float ik = 1.0f / (1.0f - p.drop_p);
+            if constexpr (DROP == 2) {
+#pragma unroll
+                for (int t = 0; t < 2 * NKP; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        S[t][e] = (((4 * t + e < 32 ? mb[i].x : mb[i].y) >> ((4 * t + e) & 31)) & 1u) ? S[t][e] * ik : 0.f;
+            } else {
+                const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * ((p.Tk + 3) & ~3);
+#pragma unroll
+                for (int t = 0; t < 2 * NKP; ++t) {
+                    float m4[4];
+                    drop_mult4(p.drop_seed, p.drop_stream, base + (16 * t + 4 * g), p.drop_p, ik, m4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[t][e] *= m4[e];
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        f32x4 O[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) O[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < NKP; ++tp) {
+            const bf16x8 pf = pack8(S[2 * tp], S[2 * tp + 1]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) O[n] = mfma(tr_frag(Vs, 32 * tp, n, lane), pf, O[n]);
+        }
+        if (qrow < p.Tq) {
+            const float inv = 1.0f / sum;
+            bf16_t* o = (bf16_t*)p.o + (long long)b * p.o_bs + (long long)qrow * p.o_rs + (long long)h * 64 + 4 * g;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(O[n][e] * inv);
+                *(bf16x4*)(o + 16 * n) = ov;
+            }
+            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Tq + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- forward, T > 256
 // Same register-resident-P scheme, keys streamed through LDS in chunks of 128 with an online softmax: a workgroup owns 128 queries
 // (8 wavefronts x 16) of one (batch, head); per chunk a wavefront computes S^T (8 tiles), folds the chunk maximum into its running
@@ -726,18 +860,29 @@ bool short_enabled() {
 
 bool al8(const void* ptr, long long bs, long long rs) { return ((uintptr_t)ptr % 8 == 0) && (bs % 4 == 0) && (rs % 4 == 0); }
 
+bool v2_enabled() {                                             // AVAMD_ATTN_V2=0: the kernels with register staging (older path, kept for A/B)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AVAMD_ATTN_V2");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+
 template <int NKP, int DROP>
 int launch_fwd_short2(const AttnP& p, hipStream_t st) {
     const int lds = 2 * NKP * 32 * 64 * 2;
     static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_short_kernel<NKP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)attn_fwd_short_kernel<NKP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_fwd_short2_kernel<NKP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             av_set_error("av_attention_fwd: cannot raise dynamic LDS to %d", lds);
             return AV_ERR_LAUNCH;
         }
         done = true;
     }
-    hipLaunchKernelGGL((attn_fwd_short_kernel<NKP, DROP>), dim3((unsigned)p.H, (unsigned)p.B), dim3(NT), lds, st, p);
+    if (v2_enabled()) hipLaunchKernelGGL((attn_fwd_short2_kernel<NKP, DROP>), dim3((unsigned)p.H, (unsigned)p.B), dim3(NT), lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_short_kernel<NKP, DROP>), dim3((unsigned)p.H, (unsigned)p.B), dim3(NT), lds, st, p);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -750,7 +895,8 @@ template <int DROP>
 int launch_bwd_short(const BwdP& p, int R, int lds, hipStream_t st) {
     static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute((const void*)attn_bwd_short_kernel<DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 64 * 2 + 2 * 256 * 4 + 16 * 64 * 8) != hipSuccess) {
+        const int mx = 2 * 256 * 64 * 2 + 2 * 256 * 4 + 16 * 64 * 8;
+        if (hipFuncSetAttribute((const void*)attn_bwd_short_kernel<DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) {
             av_set_error("av_attention_bwd: cannot raise dynamic LDS");
             return AV_ERR_LAUNCH;
         }

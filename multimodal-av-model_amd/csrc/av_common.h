@@ -94,6 +94,13 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     const float cdf = 0.5f + (x < 0.f ? -0.5f : 0.5f) * e;
     return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
+// gelu(x) and gelu'(x) from ONE erf evaluation (AV_ACT_GELU_GF)
+__device__ __forceinline__ void gelu_both_fast(float x, float& gl, float& gp) {
+    const float e = erf_abs_poly(fabsf(x) * 0.70710678118654752440f);
+    const float t = 0.5f * x;
+    gl = t + fabsf(t) * e;
+    gp = 0.5f + (x < 0.f ? -0.5f : 0.5f) * e + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---- counter-based RNG (Philox2x32-10, Salmon et al. SC'11) for dropout: the mask of element `idx` of stream `stream` under `seed`

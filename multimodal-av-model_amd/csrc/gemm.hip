@@ -294,10 +294,17 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const av_gemm_args p, const in
                 if (nok && m < p.M) {
                     float v = acc[i][j][e] * p.alpha + bias;
                     const long long off = cbase + (long long)m * p.ldc + n;
-                    if (p.C2) st_any(p.C2, off, p.out_dtype, v);
-                    if (p.act == AV_ACT_GELU) v = gelu_f(v);
-                    else if (p.act == AV_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(ld_any(p.aux, off, p.aux_dtype));
-                    if (p.drop_p > 0.f) v *= drop_mult_call(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                    if (p.act == AV_ACT_GELU_GF) {               // C2 = gelu'(v) * m, v = gelu(v) * m
+                        const float mlt = p.drop_p > 0.f ? drop_mult_call(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, 1.0f / (1.0f - p.drop_p)) : 1.f;
+                        if (p.C2) st_any(p.C2, off, p.out_dtype, gelu_grad_f(v) * mlt);
+                        v = gelu_f(v) * mlt;
+                    } else {
+                        if (p.C2) st_any(p.C2, off, p.out_dtype, v);
+                        if (p.act == AV_ACT_GELU) v = gelu_f(v);
+                        else if (p.act == AV_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(ld_any(p.aux, off, p.aux_dtype));
+                        else if (p.act == AV_ACT_MUL_AUX) v *= ld_any(p.aux, off, p.aux_dtype);
+                        if (p.drop_p > 0.f) v *= drop_mult_call(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                    }
                     if (R) v += R[(long long)m * p.ldr + n];
                     st_any(p.C, off, p.out_dtype, v);
                     csum[j] += v; csq[j] += v * v;
@@ -379,7 +386,8 @@ extern "C" int av_gemm(const av_gemm_args* a, void* stream) {
     AV_CHECK(p.in_dtype == AV_F32 || p.in_dtype == AV_BF16, "av_gemm: bad in_dtype %d", p.in_dtype);
     AV_CHECK(p.out_dtype == AV_F32 || p.out_dtype == AV_BF16, "av_gemm: bad out_dtype %d", p.out_dtype);
     AV_CHECK(!(p.stats && p.batch != 1), "av_gemm: stats need batch == 1");
-    AV_CHECK(!(p.act == AV_ACT_MUL_GELU_GRAD && !p.aux), "av_gemm: MUL_GELU_GRAD needs aux");
+    AV_CHECK(!((p.act == AV_ACT_MUL_GELU_GRAD || p.act == AV_ACT_MUL_AUX) && !p.aux), "av_gemm: MUL_GELU_GRAD / MUL_AUX need aux");
+    AV_CHECK(p.act >= AV_ACT_NONE && p.act <= AV_ACT_MUL_AUX, "av_gemm: unknown activation %d", p.act);
     AV_CHECK(p.drop_p >= 0.f && p.drop_p < 1.f, "av_gemm: drop_p=%f out of [0,1)", p.drop_p);
     if (p.M == 0 || p.N == 0) return AV_OK;
     const long long es = p.in_dtype == AV_F32 ? 4 : 2;

@@ -29,6 +29,8 @@ from ..utils.shadow import ParamCache
 Tensor = torch.Tensor
 # attention-dropout keep bits evaluated once per step on a side stream (0: every kernel generates its masks itself; A/B runs)
 DROP_BITS = os.environ.get("AVAMD_ATTN_DROPBITS", "1") != "0"
+# FFN activation site saves its gradient factor instead of the pre-activation (bf16 mode); AVAMD_FFN_GF=0 = recompute gelu' and the mask in the backward
+FFN_GF = os.environ.get("AVAMD_FFN_GF", "1") != "0"
 # the second audio pass of a step runs on its own stream beside the first (HBM-bound row kernels of one pass overlap MFMA-bound GEMMs of the other)
 PASS_STREAMS = os.environ.get("AVAMD_PASS_STREAMS", "1") != "0"
 
@@ -341,14 +343,17 @@ class Wav2Vec2ModelHIP(nn.Module):
             x2, mu2, rs2 = ops.layernorm_fwd(h2, self.P(p + "final_layer_norm.weight").data, self.P(p + "final_layer_norm.bias").data,
                                              out_dtype=dtype, eps=eps, save_stats=True)
             u = torch.empty((B, T, cfg["intermediate_size"]), dtype=dtype, device=dev) if keep_ctx else None
+            # bf16: the saved tensor is the site's gradient factor gelu'(u) o mask / (1 - p) instead of u, so the dX product of the
+            # backward ends in one multiply (no erf / exp / mask regeneration while its matrix pipe waits)
+            gf = FFN_GF and keep_ctx and dtype == torch.bfloat16
             g = ops.linear(x2, self.c(p + "feed_forward.intermediate_dense.weight", dtype),
-                           self.P(p + "feed_forward.intermediate_dense.bias").data, out_dtype=dtype, act=L.ACT_GELU, C2=u,
+                           self.P(p + "feed_forward.intermediate_dense.bias").data, out_dtype=dtype, act=L.ACT_GELU_GF if gf else L.ACT_GELU, C2=u,
                            drop=(ac_p, seed, li * 8 + 1))
             h3 = ops.linear(g, self.c(p + "feed_forward.output_dense.weight", dtype), self.P(p + "feed_forward.output_dense.bias").data,
                             out_dtype=torch.float32, R=h2, drop=(hd_p, seed, li * 8 + 2))
             if keep_ctx:
                 tr = train[li]
-                saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, lse=lse, amask=amask, h2=h2, mu2=mu2, rs2=rs2, u=u,
+                saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, lse=lse, amask=amask, h2=h2, mu2=mu2, rs2=rs2, u=u, gf=gf,
                                  x1=x1 if tr else None, x2=x2 if tr else None, g=g if tr else None)
             h = h3
         last, muf, rsf = ops.layernorm_fwd(h, self.P("encoder.layer_norm.weight").data, self.P("encoder.layer_norm.bias").data,
@@ -468,8 +473,11 @@ class Wav2Vec2ModelHIP(nn.Module):
         dh3 = dh
         dh3_t = dh_lp if (fuse_lp and dh_lp is not None) else ops.cast_dropout(dh3, dtype, (hd_p, seed, li * 8 + 2))   # FFN-output dropout mask
         W2 = self.c(p + "feed_forward.output_dense.weight", dtype)            # [Hd, I]
-        du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I), b_is_weight=True,
-                           drop=(ac_p, seed, li * 8 + 1))
+        if s.get("gf"):                                              # s["u"] holds gelu'(u) o mask / (1 - p)
+            du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_AUX, aux=s["u"].view(M, I), b_is_weight=True)
+        else:
+            du = ops.matmul_nn(dh3_t.view(M, Hd), W2, out_dtype=dtype, act=L.ACT_MUL_GELU_GRAD, aux=s["u"].view(M, I), b_is_weight=True,
+                               drop=(ac_p, seed, li * 8 + 1))
         if tr:
             wgrad(p + "feed_forward.output_dense.weight", dh3_t.view(M, Hd), s["g"].view(M, I))
             bgrad(p + "feed_forward.output_dense.bias", (dh3_t if hd_p > 0 else dh3).view(M, Hd))

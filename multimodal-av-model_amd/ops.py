@@ -139,7 +139,9 @@ def gemm(A: Tensor, B: Tensor, C_: Tensor, *, M: int, N: int, K: int, lda: int, 
         es, oes = A.element_size(), C_.element_size()
         nbytes = batch * ((M * K + N * K) * es + M * N * (oes + (4 if R is not None else 0) + (aux.element_size() if aux is not None else 0)
                                                           + (oes if C2 is not None else 0)))
-        pr["records"].append((e0, e1, 2.0 * M * N * K * batch, float(nbytes)))
+        pr["records"].append((e0, e1, 2.0 * M * N * K * batch, float(nbytes),
+                              (M, N, K, batch, act, bias is not None, R is not None, aux is not None, C2 is not None,
+                               drop is not None and drop[0] > 0, bool(conv), stats is not None)))
         return C_
     L.check(L.lib().av_gemm(C.byref(a), stream()), "av_gemm")
     return C_

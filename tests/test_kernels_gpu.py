@@ -79,6 +79,40 @@ def test_linear_epilogues(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,p", [(200, 192, 160, 0.0), (200, 192, 160, 0.25), (600, 512, 256, 0.1), (130, 70, 64, 0.1)])
+def test_gelu_gradient_factor_epilogues(dtype, M, N, K, p):
+    """AV_ACT_GELU_GF writes C = gelu(v) o m and C2 = gelu'(v) o m (m = the dropout multiplier of (seed, stream, m * ldc + n), the
+    same mask AV_ACT_GELU + dropout applies); AV_ACT_MUL_AUX multiplies a product by such a saved factor.  Together they equal the
+    recomputing pair AV_ACT_GELU / AV_ACT_MUL_GELU_GRAD with the same dropout triple (hf:565-572 and its backward)."""
+    x = _rand(M, K, dtype=dtype); w = _rand(N, K, dtype=dtype, scale=1 / math.sqrt(K)); b = _rand(N)
+    drop = (p, 4242, 5) if p > 0 else None
+    gf = torch.empty(M, N, device="cuda", dtype=dtype)
+    y = ops.linear(x, w, b, out_dtype=dtype, act=L.ACT_GELU_GF, C2=gf, drop=drop)
+    pre = torch.empty(M, N, device="cuda", dtype=dtype)
+    y_ref = ops.linear(x, w, b, out_dtype=dtype, act=L.ACT_GELU, C2=pre, drop=drop)
+    torch.testing.assert_close(y.float(), y_ref.float(), **_tol(dtype))
+    ref_pre = (_ref_mm(x, w.t()) + b).requires_grad_(True)
+    torch.nn.functional.gelu(ref_pre).sum().backward()
+    keep = torch.ones(M, N, device="cuda", dtype=torch.bool)
+    if p > 0:                                                   # the mask itself: element index = m * ldc + n
+        uni = torch.empty(M * N, device="cuda", dtype=torch.float32)
+        L.check(L.lib().av_dropout_uniform(ops.ptr(uni), M * N, drop[1], drop[2], ops.stream()))
+        keep = (uni >= p).view(M, N)
+        torch.testing.assert_close(y.float(), torch.nn.functional.gelu(ref_pre.detach()) * keep.float() / (1.0 - p), **_tol(dtype))
+    mult = keep.float() / (1.0 - p)
+    torch.testing.assert_close(gf.float(), ref_pre.grad * mult, **_tol(dtype))
+    if p > 0:
+        assert 0.5 * p < 1.0 - keep.float().mean().item() < 1.5 * p
+    # backward: dY W o gf == (dY W o gelu'(pre)) o mask
+    dy = _rand(M, K, dtype=dtype)
+    du = ops.linear(dy, w, None, out_dtype=torch.float32, act=L.ACT_MUL_AUX, aux=gf)
+    du_ref = ops.linear(dy, w, None, out_dtype=torch.float32, act=L.ACT_MUL_GELU_GRAD, aux=pre, drop=drop)
+    t = _tol(dtype)
+    torch.testing.assert_close(du, du_ref, rtol=max(t["rtol"], 2e-2 if dtype == torch.bfloat16 else 0), atol=t["atol"])
+    torch.testing.assert_close(du, _ref_mm(dy, w.t()) * gf.float(), **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(130, 96, 200), (64, 64, 64), (257, 1024, 129), (200, 70, 33)])
 def test_matmul_nn_tn(dtype, M, N, K):
     a = _rand(M, K, dtype=dtype); b = _rand(K, N, dtype=dtype, scale=1 / math.sqrt(K))
