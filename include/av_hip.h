@@ -281,6 +281,28 @@ int av_adam_multi_scaled(const void* ptrs, const long long* sizes, const float* 
                          int n_chunks, int chunk_elems, float beta1, float beta2, float eps, float grad_scale, float* scaler_state,
                          float growth, float backoff, int growth_interval, void* stream);
 
+/* ---- legacy mel + GRU model (reference: "이전 버전/multimodal_ctc_korean.py":8-55, train loop
+ * "이전 버전/train_ctc_korea.py":82-109).  Its convolutions (nn.Conv2d 3x3, :12,15) and all input / weight-gradient products run on
+ * av_gemm; these entry points are the rest of it:
+ * av_nchw_to_nhwc:      frames [N][C][H][W] fp32 (the (B*T, C, H, W) view of :23) -> [N][H][W][Cp] channel-last, zero padded to Cp
+ * av_relu_maxpool2_fwd: y = MaxPool2d(2)(ReLU(x)) (:13-14,16-17), x [N][H][W][C]; y [N][H/2][W/2][C] or, nchw_out = 1,
+ *                       [N][C][H/2][W/2] = the (C, H', W') flatten order the GRU input uses (:25)
+ * av_relu_maxpool2_bwd: dx = dy routed to the first maximum of each 2x2 window where x > 0 (torch max_pool2d / relu backward)
+ * av_im2col3:           cols [(n,h,w)][(ky,kx,c)] of a 3x3 / stride 1 / pad 1 window: k-major operand of dW = dY^T cols
+ * av_gru_fwd_step / av_gru_bwd_step: nn.GRU(hidden, 2 layers, bidirectional) time steps (:19,32; gate order r, z, n;
+ *   h = (1 - z) n + z h_prev), both directions per launch, time-major buffers as av_lstm_*_step: gx [T][B][2][3H] = x W_ih^T + b_ih
+ *   from av_gemm; hseq [T][B][2H] compute dtype; hf [T][B][2][H] fp32 state; gates [T][B][2][4H] = (r, z, n, W_hn h + b_hn);
+ *   backward (s counts from the END of each chain): dgi / dgh [T][B][2][3H] from dout[t] + dgh[t_next] W_hh + the direct path
+ *   dh o z carried in dhc [2][B][H] */
+int av_nchw_to_nhwc(const float* in, void* out, int out_dtype, long long N, int C, int H, int W, int Cp, void* stream);
+int av_relu_maxpool2_fwd(const void* x, void* y, int dtype, long long N, int H, int W, int C, int nchw_out, void* stream);
+int av_relu_maxpool2_bwd(const void* x, const void* dy, void* dx, int dtype, long long N, int H, int W, int C, int nchw_dy, void* stream);
+int av_im2col3(const void* x, void* cols, int dtype, long long N, int H, int W, int C, void* stream);
+int av_gru_fwd_step(const float* gx, const void* whh, const float* bhh, void* hseq, float* hf, float* gates, void* out_bt, int dtype,
+                    int T, int B, int H, int s, void* stream);
+int av_gru_bwd_step(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgi, void* dgh, const void* whhT,
+                    const float* gates, const float* hf, float* dhc, int dtype, int T, int B, int H, int s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

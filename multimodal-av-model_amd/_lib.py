@@ -97,6 +97,12 @@ SIGNATURES = {
     "av_adam_multi_scaled": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, f32, f32, i32, vp],
     "av_adam_step": [vp, vp, vp, vp, ll, f32, f32, f32, f32, i32, f32, vp],
     "av_softmax_bwd_rows": [vp, i32, vp, vp, i32, ll, i32, f32, i32, vp],
+    "av_nchw_to_nhwc": [vp, vp, i32, ll, i32, i32, i32, i32, vp],
+    "av_relu_maxpool2_fwd": [vp, vp, i32, ll, i32, i32, i32, i32, vp],
+    "av_relu_maxpool2_bwd": [vp, vp, vp, i32, ll, i32, i32, i32, i32, vp],
+    "av_im2col3": [vp, vp, i32, ll, i32, i32, i32, vp],
+    "av_gru_fwd_step": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "av_gru_bwd_step": [vp, i32, ll, ll, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
 }
 _RESTYPES = {"av_last_error": C.c_char_p}
 

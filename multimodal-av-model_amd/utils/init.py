@@ -141,3 +141,50 @@ def projection_params(d: int, out: int = 128, seed: int = 5) -> Tuple[torch.Tens
     g = _Gen(seed)
     k = 1.0 / math.sqrt(d)
     return g.uniform((out, d), -k, k), g.uniform((out,), -k, k)
+
+
+def legacy_state_dict(vocab_size: int = 200, hidden_dim: int = 256, seed: int = 7, in_channels: int = 3, mel_dim: int = 80
+                      ) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded state_dict of the legacy mel + GRU model (key names of 이전 버전/multimodal_ctc_korean.py:8-55: lip_encoder.cnn.{0,3}.*,
+    lip_encoder.rnn.*, audio_encoder.rnn.*, fc.*)."""
+    g = _Gen(seed)
+    sd = OrderedDict()
+    sd["lip_encoder.cnn.0.weight"] = g.normal((32, in_channels, 3, 3), math.sqrt(2.0 / (9 * in_channels)))
+    sd["lip_encoder.cnn.0.bias"] = g.normal((32,), 0.05)
+    sd["lip_encoder.cnn.3.weight"] = g.normal((64, 32, 3, 3), math.sqrt(2.0 / (9 * 32)))
+    sd["lip_encoder.cnn.3.bias"] = g.normal((64,), 0.05)
+    H = hidden_dim
+    for pre, in0 in (("lip_encoder.rnn.", 64 * 24 * 24), ("audio_encoder.rnn.", mel_dim)):
+        for layer in range(2):
+            in_f = in0 if layer == 0 else 2 * H
+            for suf in ("", "_reverse"):
+                sd[f"{pre}weight_ih_l{layer}{suf}"] = g.normal((3 * H, in_f), 1.0 / math.sqrt(in_f))
+                sd[f"{pre}weight_hh_l{layer}{suf}"] = g.normal((3 * H, H), 1.0 / math.sqrt(H))
+                sd[f"{pre}bias_ih_l{layer}{suf}"] = g.normal((3 * H,), 0.05)
+                sd[f"{pre}bias_hh_l{layer}{suf}"] = g.normal((3 * H,), 0.05)
+    sd["fc.weight"] = g.normal((vocab_size, 4 * H), 1.0 / math.sqrt(4 * H))
+    sd["fc.bias"] = g.normal((vocab_size,), 0.02)
+    return sd
+
+
+def legacy_batch(batch: int, steps: int, vocab_size: int, seed: int = 11, label_len: int = None, size: int = 96, mel_dim: int = 80):
+    """Synthetic batch in the layout of the legacy collate_fn (이전 버전/train_ctc_korea.py:54-77): frames U[0,1) [B,T,3,96,96] (:30),
+    mel >= 0 [B,T,80], labels time-major (L, B) without blanks or repeats, lengths."""
+    g = _Gen(seed)
+    L_ = label_len or batch
+    fa = g.uniform((batch, steps, 3, size, size), 0.0, 1.0)
+    fb = g.uniform((batch, steps, 3, size, size), 0.0, 1.0)
+    mel = g.normal((batch, steps, mel_dim), 1.0).abs()
+    mel_len = torch.full((batch,), steps, dtype=torch.long)
+
+    def labels():
+        lab = torch.zeros((L_, batch), dtype=torch.long)
+        for b in range(batch):
+            perm = torch.randperm(vocab_size - 1, generator=g.g)[:L_] + 1        # distinct non-blank ids
+            lab[:, b] = perm
+        lens = torch.randint(1, min(L_, max(1, steps // 2)) + 1, (L_ if False else batch,), generator=g.g)
+        return lab, lens
+
+    la, na = labels()
+    lb, nb = labels()
+    return fa, fb, mel, mel_len, la, na, lb, nb

@@ -88,3 +88,24 @@ def test_pipeline_oracle_known_answers():
     assert m1.tolist() == [1, 1, 1, 0, 0] and m2.tolist() == [1, 1, 1, 2, 2]
     mixed, m1, m2 = po.mix_pair(a2, a2)
     assert m1.tolist() == [1, 1, 1] == m2.tolist()
+
+
+def test_legacy_oracle_vs_reference_fixture():
+    """oracle/legacy_oracle.py against tests/golden/legacy_tiny.npz = outputs of the reference's legacy model."""
+    from oracle import legacy_oracle as LO
+    init = pkg("utils.init")
+    fx = np.load(os.path.join(GOLD, "legacy_tiny.npz"))
+    vocab, hidden, B, T, seed_w, seed_b = (int(x) for x in fx["cfg"])
+    sd = init.legacy_state_dict(vocab, hidden, seed_w)
+    batch = init.legacy_batch(B, T, vocab, seed_b)
+    before = {k: v.clone() for k, v in sd.items()}
+    out, grads = LO.train_step(sd, batch, {}, lr=1e-4)
+    assert np.abs(out["logits_A"].numpy() - fx["logits_A"]).max() < 1e-4
+    assert np.abs(out["logits_B"].numpy() - fx["logits_B"]).max() < 1e-4
+    assert abs(float(out["loss"]) - float(fx["loss"])) < 1e-4
+    for k, g in grads.items():
+        flat = g.flatten()
+        idx = torch.linspace(0, flat.numel() - 1, min(48, flat.numel())).long()
+        gs = fx["gslice/" + k]
+        assert np.abs(flat[idx].numpy() - gs).max() < 1e-3 * max(np.abs(gs).max(), 1e-6) + 1e-8, k
+        assert abs(float(flat.norm()) - float(fx["gnorm/" + k])) < 1e-3 * float(fx["gnorm/" + k]) + 1e-8, k
