@@ -303,6 +303,17 @@ int av_gru_fwd_step(const float* gx, const void* whh, const float* bhh, void* hs
 int av_gru_bwd_step(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgi, void* dgh, const void* whhT,
                     const float* gates, const float* hf, float* dhc, int dtype, int T, int B, int H, int s, void* stream);
 
+/* file decoding + resampling of the input pipeline (dataset/multi_speaker_dataset.py:15-19 `librosa.load(path, sr=16000)`):
+ * av_wav_info / av_wav_read_mono_f32 are HOST-side file I/O (RIFF/WAVE: PCM 8/16/24/32 bit, IEEE float 32/64; float32 mono =
+ *   mean over channels of libsndfile-scaled samples, i.e. what librosa holds before it resamples); `out` is HOST memory;
+ * av_resample_sinc (device): Kaiser-windowed-sinc interpolation with a linearly interpolated filter table (win / delta [nwin],
+ *   num_table entries per zero crossing, already scaled by min(1, sr_out / sr_in)); n_out = ceil(n_in * sr_out / sr_in).
+ *   librosa resamples with soxr_hq, whose filter is not published as a formula: this stage is "parity unpinned" (DESIGN 0, (f)-2). */
+int av_wav_info(const char* path, int* sample_rate, int* channels, long long* frames, int* bits, int* is_float);
+int av_wav_read_mono_f32(const char* path, long long frame0, long long n, float* out);
+int av_resample_sinc(const float* x, long long n_in, float* y, long long n_out, const float* win, const float* delta, int nwin, int num_table,
+                     int sr_in, int sr_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

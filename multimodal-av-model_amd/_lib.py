@@ -103,6 +103,9 @@ SIGNATURES = {
     "av_im2col3": [vp, vp, i32, ll, i32, i32, i32, vp],
     "av_gru_fwd_step": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "av_gru_bwd_step": [vp, i32, ll, ll, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "av_wav_info": [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(ll), C.POINTER(i32), C.POINTER(i32)],
+    "av_wav_read_mono_f32": [C.c_char_p, ll, ll, vp],
+    "av_resample_sinc": [vp, ll, vp, ll, vp, vp, i32, i32, i32, i32, vp],
 }
 _RESTYPES = {"av_last_error": C.c_char_p}
 

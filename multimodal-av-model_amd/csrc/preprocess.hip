@@ -65,6 +65,44 @@ __global__ __launch_bounds__(256) void mix_finish_kernel(const float* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- band-limited resampling
+// y[t] = sum over both wings of a Kaiser-windowed sinc evaluated at the fractional position of output sample t (table with linear
+// interpolation between entries: `win` / `delta`, `num_table` entries per zero crossing) - the published "windowed-sinc with
+// interpolated table" law (J. O. Smith, "Digital Audio Resampling", as implemented by resampy): for down-sampling the filter is
+// stretched by `scale` = sr_out / sr_in and its gain scaled by the same factor (done on the table by the caller).
+__global__ __launch_bounds__(256) void resample_sinc_kernel(const float* __restrict__ x, long long n_in, float* __restrict__ y, long long n_out,
+                                                            const float* __restrict__ win, const float* __restrict__ delta, int nwin, int num_table,
+                                                            double time_increment, double scale) {
+    const int index_step = (int)(scale * num_table);
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n_out; t += (long long)gridDim.x * 256) {
+        const double time_register = (double)t * time_increment;
+        const long long n = (long long)time_register;
+        double frac = scale * (time_register - (double)n);
+        double index_frac = frac * num_table;
+        int offset = (int)index_frac;
+        double eta = index_frac - offset;
+        double acc = 0.0;
+        long long i_max = (nwin - offset) / index_step;
+        if (i_max > n + 1) i_max = n + 1;
+        for (long long i = 0; i < i_max; ++i) {                  // left wing: x[n], x[n - 1], ...
+            const int k = offset + (int)i * index_step;
+            acc += ((double)win[k] + eta * (double)delta[k]) * (double)x[n - i];
+        }
+        frac = scale - frac;                                       // right wing: x[n + 1], x[n + 2], ...
+        index_frac = frac * num_table;
+        offset = (int)index_frac;
+        eta = index_frac - offset;
+        long long k_max = (nwin - offset) / index_step;
+        if (k_max > n_in - n - 1) k_max = n_in - n - 1;
+        for (long long k = 0; k < k_max; ++k) {
+            const int j = offset + (int)k * index_step;
+            acc += ((double)win[j] + eta * (double)delta[j]) * (double)x[n + k + 1];
+        }
+        y[t] = (float)acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int av_lip_gray_resize(const void* src, int src_is_u8, float* dst, int T, int Hs, int Ws, int C, int Hd, int Wd, float divisor, void* stream) {
@@ -94,6 +132,22 @@ extern "C" int av_mix_pair(const float* a1, long long len1, const float* a2, lon
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(mix_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a1, len1, a2, len2, n, peak_ws);
     hipLaunchKernelGGL(mix_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a1, len1, a2, len2, n, peak_ws, mixed, mask1, mask2);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_resample_sinc(const float* x, long long n_in, float* y, long long n_out, const float* win, const float* delta, int nwin, int num_table,
+                                int sr_in, int sr_out, void* stream) {
+    AV_CHECK(n_in >= 0 && n_out >= 0 && nwin > 0 && num_table > 0 && sr_in > 0 && sr_out > 0, "av_resample_sinc: bad args");
+    if (n_out == 0) return AV_OK;
+    AV_CHECK(x && y && win && delta && n_in > 0, "av_resample_sinc: null pointer");
+    const double ratio = (double)sr_out / (double)sr_in;
+    const double scale = ratio < 1.0 ? ratio : 1.0;
+    AV_CHECK((int)(scale * num_table) >= 1, "av_resample_sinc: rate ratio %d -> %d too small for a table of %d entries per zero crossing", sr_in, sr_out, num_table);
+    long long blocks = (n_out + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(resample_sinc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n_in, y, n_out, win, delta, nwin, num_table,
+                       1.0 / ratio, scale);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

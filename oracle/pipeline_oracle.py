@@ -63,3 +63,51 @@ def lips(frames: np.ndarray, size: int = 96) -> np.ndarray:
     gray = (s / np.float32(x.shape[-1])).astype(np.float32)
     out = np.stack([resize_bilinear(f, size, size) for f in gray]) if len(gray) else np.zeros((0, size, size), np.float32)
     return (out / np.float32(255.0)).astype(np.float32)[:, None]
+
+
+# ---- band-limited resampling (the stage librosa.load(path, sr=16000) adds when the file's rate differs, :15,18) -------------------
+# librosa's default resampler is soxr_hq (not installed here, filter not published as a formula): **parity unpinned**.  What is
+# restated is the published windowed-sinc-with-interpolated-table law (J. O. Smith, "Digital Audio Resampling"; resampy's
+# "kaiser_best" parameters), which the device kernel implements; known answers (identity, pure tones) pin this restatement.
+def sinc_table(ratio: float, num_zeros: int = 64, precision: int = 9, rolloff: float = 0.9475937167399596, beta: float = 14.769656459379492):
+    num_table = 2 ** precision
+    n = num_table * num_zeros
+    win = np.kaiser(2 * n + 1, beta)[n:] * (rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True)))
+    if ratio < 1.0:
+        win = win * ratio
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    return win.astype(np.float32).astype(np.float64), delta.astype(np.float32).astype(np.float64), num_table
+
+
+def resample_sinc(x: np.ndarray, sr_in: int, sr_out: int) -> np.ndarray:
+    """float32 [n] at sr_in -> float32 [ceil(n * sr_out / sr_in)] at sr_out (double accumulation, float32 table)."""
+    x = np.asarray(x, dtype=np.float32)
+    if sr_in == sr_out:
+        return x
+    ratio = float(sr_out) / float(sr_in)
+    win, delta, num_table = sinc_table(ratio)
+    nwin = len(win)
+    scale = min(1.0, ratio)
+    index_step = int(scale * num_table)
+    n_in = len(x)
+    n_out = int(np.ceil(n_in * ratio))
+    t = np.arange(n_out, dtype=np.float64) * (1.0 / ratio)
+    n = t.astype(np.int64)
+    xd = x.astype(np.float64)
+    y = np.zeros(n_out, dtype=np.float64)
+    frac = scale * (t - n)
+    for wing in (0, 1):
+        if wing == 1:
+            frac = scale - frac
+        index_frac = frac * num_table
+        offset = index_frac.astype(np.int64)
+        eta = index_frac - offset
+        cnt = (nwin - offset) // index_step
+        cnt = np.minimum(cnt, n + 1 if wing == 0 else n_in - n - 1)
+        for i in range(int(cnt.max()) if n_out else 0):
+            m = cnt > i
+            k = offset[m] + i * index_step
+            src = n[m] - i if wing == 0 else n[m] + i + 1
+            y[m] += (win[k] + eta[m] * delta[k]) * xd[src]
+    return y.astype(np.float32)
