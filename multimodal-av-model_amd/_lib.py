@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavhip.so")
+LIB_PATH = os.environ.get("AVAMD_LIB") or os.path.join(_HERE, "libavhip.so")      # AVAMD_LIB: another build of the same library (A/B tooling)
 
 AV_F32, AV_BF16 = 0, 1
 A_ROWMAJOR, A_TRANS, A_CONV2D, A_CONV3D1 = 0, 1, 2, 3

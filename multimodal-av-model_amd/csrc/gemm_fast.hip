@@ -134,98 +134,107 @@ __device__ __forceinline__ void stage_conv(const av_gemm_args& p, const ConvRows
     }
 }
 
-struct FastFlags { int c_vec, r_vec, aux_vec, pre; };    // pre: epilogue operands requested four rows ahead (AVAMD_EPI_PREFETCH=0 disables)
+struct FastFlags { int c_vec, r_vec, aux_vec; };
 
-// pre-activation copy / activation / dropout of 8 consecutive columns (everything between the bias and the residual)
-__device__ __forceinline__ void store8(void* base, long long off, int dtype, const float (&v)[8], bool vec, int gn, int N) {
-    if (vec) {
-        if (dtype == AV_BF16) {
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-            *(bf16x8*)((bf16_t*)base + off) = o;
-        } else {
-            *(f32x4*)((float*)base + off) = f32x4{v[0], v[1], v[2], v[3]};
-            *(f32x4*)((float*)base + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (gn + e < N) st_any(base, off + e, dtype, v[e]);
-    }
-}
-__device__ __forceinline__ void drop_mult8(const av_gemm_args& p, long long off, float (&m)[8]) {
-    const float ik = 1.0f / (1.0f - p.drop_p);
-    if ((off & 3) == 0) {                                       // off is a multiple of 4 whenever ldc % 4 == 0 (gn % 8 == 0)
-        float m4[4];
-        drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = m4[e];
-        drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off + 4, p.drop_p, ik, m4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[4 + e] = m4[e];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
-    }
-}
-__device__ __forceinline__ void epilogue_act(const av_gemm_args& p, const FastFlags& fl, float (&v)[8], long long off, int gn, bool full,
-                                             bool have_aux = false, bf16x8 auxval = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}) {
+// shared tail of the coalesced epilogue: optional pre-activation copy, activation, dropout, residual, store (8 columns)
+__device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const FastFlags& fl, float (&v)[8], long long off, int gm, int gn, bool full,
+                                               const float* R) {
     if (p.act == AV_ACT_GELU_GF) {
-        // activation + dropout site whose backward is a plain multiply: C2 = gelu'(v) * m, v = gelu(v) * m (m = dropout multiplier):
-        // the dX product of the layer above then ends in AV_ACT_MUL_AUX - no erf / exp / Philox while its MFMA pipe waits
+        // activation + dropout site whose backward is a plain multiply: C2 = gelu'(v) * m, v = gelu(v) * m (m = dropout multiplier); the dX
+        // product of the layer above then ends in AV_ACT_MUL_AUX - no erf / exp / Philox while its matrix pipe waits
         float m[8], gf[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) m[e] = 1.f;
-        if (p.drop_p > 0.f) drop_mult8(p, off, m);
+        if (p.drop_p > 0.f) {
+            const float ik = 1.0f / (1.0f - p.drop_p);
+            if ((off & 3) == 0) {
+                float m4[4];
+                drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = m4[e];
+                drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off + 4, p.drop_p, ik, m4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[4 + e] = m4[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float gl, gp;
             gelu_both_fast(v[e], gl, gp);
             v[e] = gl * m[e]; gf[e] = gp * m[e];
         }
-        if (p.C2) store8(p.C2, off, p.out_dtype, gf, full && fl.c_vec, gn, p.N);
-        return;
+        if (p.C2) {
+            if (full && fl.c_vec && p.out_dtype == AV_BF16) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)gf[e];
+                *(bf16x8*)((bf16_t*)p.C2 + off) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C2, off + e, p.out_dtype, gf[e]);
+            }
+        }
+    } else
+    if (p.C2) {
+        if (full && fl.c_vec) {
+            if (p.out_dtype == AV_BF16) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                *(bf16x8*)((bf16_t*)p.C2 + off) = o;
+            } else {
+                *(f32x4*)((float*)p.C2 + off) = f32x4{v[0], v[1], v[2], v[3]};
+                *(f32x4*)((float*)p.C2 + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C2, off + e, p.out_dtype, v[e]);
+        }
     }
-    if (p.C2) store8(p.C2, off, p.out_dtype, v, full && fl.c_vec, gn, p.N);
     if (p.act == AV_ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
-    } else if (p.act == AV_ACT_MUL_GELU_GRAD) {
-        if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
-            const bf16x8 u = have_aux ? auxval : *(const bf16x8*)((const bf16_t*)p.aux + off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_fast(ld_any(p.aux, off + e, p.aux_dtype));
-        }
     } else if (p.act == AV_ACT_MUL_AUX) {
         if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
-            const bf16x8 u = have_aux ? auxval : *(const bf16x8*)((const bf16_t*)p.aux + off);
+            const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= ld_any(p.aux, off + e, p.aux_dtype);
         }
-    }
-    if (p.drop_p > 0.f) {
-        float m[8];
-        drop_mult8(p, off, m);
+    } else if (p.act == AV_ACT_MUL_GELU_GRAD) {
+        if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
+            const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= m[e];
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_fast(ld_any(p.aux, off + e, p.aux_dtype));
+        }
     }
-}
-
-// shared tail of the coalesced epilogue: optional pre-activation copy, activation, dropout, residual, store (8 columns)
-__device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const FastFlags& fl, float (&v)[8], long long off, int gm, int gn, bool full,
-                                               const float* R, bool have_aux = false, bf16x8 auxval = bf16x8{0, 0, 0, 0, 0, 0, 0, 0},
-                                               bool have_r = false, f32x4 rv0 = f32x4{0.f, 0.f, 0.f, 0.f}, f32x4 rv1 = f32x4{0.f, 0.f, 0.f, 0.f}) {
-    epilogue_act(p, fl, v, off, gn, full, have_aux, auxval);
+    if (p.drop_p > 0.f && p.act != AV_ACT_GELU_GF) {
+        const float ik = 1.0f / (1.0f - p.drop_p);
+        if ((off & 3) == 0) {
+            float m4[4];
+            drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= m4[e];
+            drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off + 4, p.drop_p, ik, m4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 + e] *= m4[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
+        }
+    }
     if (R) {
         const long long roff = (long long)gm * p.ldr + gn;
         if (full && fl.r_vec) {
-            const f32x4 r0 = have_r ? rv0 : *(const f32x4*)(R + roff), r1 = have_r ? rv1 : *(const f32x4*)(R + roff + 4);
+            const f32x4 r0 = *(const f32x4*)(R + roff), r1 = *(const f32x4*)(R + roff + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
         } else {
@@ -436,7 +445,98 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
         const long long off = cbase + (long long)gm * p.ldc + gn;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bv[e];
-        epilogue_act(p, fl, v, off, gn, full);
+        if (p.act == AV_ACT_GELU_GF) {
+            // activation + dropout site whose backward is a plain multiply: C2 = gelu'(v) * m, v = gelu(v) * m (m = dropout multiplier); the dX
+            // product of the layer above then ends in AV_ACT_MUL_AUX - no erf / exp / Philox while its matrix pipe waits
+            float m[8], gf[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = 1.f;
+            if (p.drop_p > 0.f) {
+                const float ik = 1.0f / (1.0f - p.drop_p);
+                if ((off & 3) == 0) {
+                    float m4[4];
+                    drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = m4[e];
+                    drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off + 4, p.drop_p, ik, m4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[4 + e] = m4[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gl, gp;
+                gelu_both_fast(v[e], gl, gp);
+                v[e] = gl * m[e]; gf[e] = gp * m[e];
+            }
+            if (p.C2) {
+                if (full && fl.c_vec && p.out_dtype == AV_BF16) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)gf[e];
+                    *(bf16x8*)((bf16_t*)p.C2 + off) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C2, off + e, p.out_dtype, gf[e]);
+                }
+            }
+        } else
+        if (p.C2) {
+            if (full && fl.c_vec) {
+                if (p.out_dtype == AV_BF16) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    *(bf16x8*)((bf16_t*)p.C2 + off) = o;
+                } else {
+                    *(f32x4*)((float*)p.C2 + off) = f32x4{v[0], v[1], v[2], v[3]};
+                    *(f32x4*)((float*)p.C2 + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C2, off + e, p.out_dtype, v[e]);
+            }
+        }
+        if (p.act == AV_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        } else if (p.act == AV_ACT_MUL_AUX) {
+            if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
+                const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= ld_any(p.aux, off + e, p.aux_dtype);
+            }
+        } else if (p.act == AV_ACT_MUL_GELU_GRAD) {
+            if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
+                const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_fast(ld_any(p.aux, off + e, p.aux_dtype));
+            }
+        }
+        if (p.drop_p > 0.f && p.act != AV_ACT_GELU_GF) {        // off is a multiple of 4 whenever ldc % 4 == 0 (gn % 8 == 0)
+            const float ik = 1.0f / (1.0f - p.drop_p);
+            if ((off & 3) == 0) {
+                float m4[4];
+                drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= m4[e];
+                drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off + 4, p.drop_p, ik, m4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 + e] *= m4[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
+            }
+        }
         if (R) {
             const long long roff = (long long)gm * p.ldr + gn;
             if (full && fl.r_vec) {
@@ -938,11 +1038,8 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = (bias && gnt + e < p.N) ? bias[gnt + e] : 0.f;
     }
-    const bool pre_aux = fl.pre && (p.act == AV_ACT_MUL_AUX || p.act == AV_ACT_MUL_GELU_GRAD) && fl.aux_vec && p.aux_dtype == AV_BF16;
-    const bool pre_r = fl.pre && R != nullptr && fl.r_vec && R != (const float*)p.C;  // a residual that aliases C is read where it is written
-    // rows half * 128 .. + 127 of the block tile: every wavefront owns 64 x 64 of them (a lambda instantiated for half = 0 and 1: the
-    // accumulator indices must stay compile-time constants, and the row-group loop inside is deliberately not unrolled)
-    auto epi_half = [&](const int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                                  // rows half * 128 .. + 127 of the block tile: every wavefront owns 64 x 64 of them
         __syncthreads();                                                    // stages / previous half's image are free
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -975,49 +1072,19 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
                     }
                 }
         }
-        // The epilogue's global operands (aux of the gelu' / gradient-factor multiply, the fp32 residual) are requested for FOUR rows at
-        // a time before the image rows are read: with one load per iteration every row paid its own round trip (the loads cannot move
-        // above the previous row's stores: may-alias), one workgroup per CU, the matrix pipe idle.
-        constexpr int NIT = 128 * CPR / V4_NT, GRP = 4;                         // 8 rows per thread and half, in two groups
         __syncthreads();
-#pragma unroll 1
-        for (int it0 = 0; it0 < NIT; it0 += GRP) {
-            bf16x8 auxv[GRP];
-            f32x4 rv[GRP][2];
-            if (pre_aux) {
+        for (int it = 0; it < 128 * CPR / V4_NT; ++it) {
+            const int id = it * V4_NT + tid;
+            const int row = id / CPR, cc = (id % CPR) * 8;
+            const int gm = m0 + half * 128 + row, gn = n0 + cc;
+            if (half * 128 + row >= rows_here || gn >= p.N) continue;
+            float v[8];
+            const f32x4 v0 = *(const f32x4*)(cs + row * V4_CLD + cc), v1 = *(const f32x4*)(cs + row * V4_CLD + cc + 4);
 #pragma unroll
-                for (int u = 0; u < GRP; ++u) {
-                    const int id = (it0 + u) * V4_NT + tid;
-                    const int row = id / CPR, cc = (id % CPR) * 8;
-                    const bool ok = half * 128 + row < rows_here && n0 + cc + 8 <= p.N;
-                    const long long off = ok ? cbase + (long long)(m0 + half * 128 + row) * p.ldc + n0 + cc : cbase + (long long)m0 * p.ldc + n0;     // clamped: always readable
-                    auxv[u] = *(const bf16x8*)((const bf16_t*)p.aux + off);
-                }
-            }
-            if (pre_r) {
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) {
-                    const int id = (it0 + u) * V4_NT + tid;
-                    const int row = id / CPR, cc = (id % CPR) * 8;
-                    const bool ok = half * 128 + row < rows_here && n0 + cc + 8 <= p.N;
-                    const long long roff = ok ? (long long)(m0 + half * 128 + row) * p.ldr + n0 + cc : (long long)m0 * p.ldr + n0;
-                    rv[u][0] = *(const f32x4*)(R + roff); rv[u][1] = *(const f32x4*)(R + roff + 4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) {
-                const int id = (it0 + u) * V4_NT + tid;
-                const int row = id / CPR, cc = (id % CPR) * 8;
-                const int gm = m0 + half * 128 + row, gn = n0 + cc;
-                if (half * 128 + row >= rows_here || gn >= p.N) continue;
-                float v[8];
-                const f32x4 v0 = *(const f32x4*)(cs + row * V4_CLD + cc), v1 = *(const f32x4*)(cs + row * V4_CLD + cc + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
-                const bool full = gn + 8 <= p.N;
-                const long long off = cbase + (long long)gm * p.ldc + gn;
-                epilogue_store(p, fl, v, off, gm, gn, full, R, pre_aux, auxv[u], pre_r, rv[u][0], rv[u][1]);
-            }
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
+            const bool full = gn + 8 <= p.N;
+            const long long off = cbase + (long long)gm * p.ldc + gn;
+            epilogue_store(p, fl, v, off, gm, gn, full, R);
         }
         if (CONV && p.stats && tid < 256 && n0 + tid < p.N && m0 + half * 128 < p.M) {
             // row block 2 mb + half of the caller's [ceil(M / 128)][2][N] buffer: the two wavefront rows' partials (scratch behind the image)
@@ -1026,9 +1093,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
             o[n0 + tid] = red[tid] + red[512 + tid];
             o[p.N + n0 + tid] = red[256 + tid] + red[768 + tid];
         }
-    };
-    epi_half(0);
-    epi_half(1);
+    }
 }
 
 template <int BNT, bool CONV, bool AKM = false, bool BKM = false>
@@ -1076,8 +1141,6 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     fl.r_vec = p.R && al16(p.R) && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
     const long long aes = p.aux_dtype == AV_F32 ? 4 : 2;
     fl.aux_vec = p.aux && al16(p.aux) && (p.ldc * aes) % 16 == 0 && (p.sC * aes) % 16 == 0 && (p.oC * aes) % 16 == 0;
-    static const int pre_on = [] { const char* e = getenv("AVAMD_EPI_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
-    fl.pre = pre_on;
     const bool narrow = p.N <= 64;
     if (akm || bkm) {
         if (p.stats || p.lda % 8) return -1;
