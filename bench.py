@@ -119,8 +119,8 @@ def attention_report(records, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json metric: batch 64)")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
