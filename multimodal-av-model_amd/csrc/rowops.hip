@@ -318,12 +318,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     if (ry == 0 && c < cols) atomicAdd(out + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
 }
 
-// bf16 rows, 16-B loads: a wavefront covers 512 consecutive columns of one row, the 4 wavefronts of a block take rows r0 + w, r0 + w + 4, ...
-constexpr int CSV_ROWS = 128;
+// bf16 rows, 16-B loads.  The kernel is bound by its atomics, not by its reads (measured: halving the rows per block doubled the atomic
+// rounds per output element and the time, 24 -> 42 us on [12736 x 1024]): a block therefore covers only 128 columns (a 16-lane group
+// reads 256 contiguous bytes of one row, a wavefront 4 rows, the 4 wavefronts 16 rows per step) but 256 rows, so an output element sees
+// rows / 256 atomic adds while [12736 x 1024] still spreads over 8 x 50 = 400 blocks with 8 loads in flight per lane.
+constexpr int CSV_ROWS = 256;
+constexpr int CSVB_COLS = 128;
 __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long long rows, int cols, long long ld) {
-    __shared__ float red[3][64][8];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 512 + lane * 8;
+    __shared__ float red[3][16][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, cg = lane & 15, rs = lane >> 4;
+    const int c = blockIdx.x * CSVB_COLS + cg * 8;
     const long long r0 = (long long)blockIdx.y * CSV_ROWS;
     long long r1 = r0 + CSV_ROWS;
     if (r1 > rows) r1 = rows;
@@ -332,31 +336,37 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
     if (c < cols) {
         const bf16_t* px = x + c;
-#pragma unroll 4
-        for (long long r = r0 + w; r < r1; r += 4) {
+#pragma unroll 8
+        for (long long r = r0 + w * 4 + rs; r < r1; r += 16) {
             const bf16x8 v = *(const bf16x8*)(px + r * ld);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
         }
     }
-    if (w > 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[w - 1][lane][e] = s[e];
+    for (int e = 0; e < 8; ++e) {                              // the four row sub-lanes of a wavefront
+        s[e] += __shfl_xor(s[e], 16, 64);
+        s[e] += __shfl_xor(s[e], 32, 64);
+    }
+    if (w > 0 && rs == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w - 1][cg][e] = s[e];
     }
     __syncthreads();
-    if (w == 0 && c < cols) {
+    if (w == 0 && rs == 0 && c < cols) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(out + c + e, s[e] + red[0][lane][e] + red[1][lane][e] + red[2][lane][e]);
+        for (int e = 0; e < 8; ++e) atomicAdd(out + c + e, s[e] + red[0][cg][e] + red[1][cg][e] + red[2][cg][e]);
     }
 }
 
 // fp32 rows, 16-B loads: a wavefront covers 256 consecutive columns of one row
+constexpr int CSVF_ROWS = 128;
 __global__ __launch_bounds__(256) void colsum_f32_vec_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows, int cols, long long ld) {
     __shared__ float red[3][64][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
-    const long long r0 = (long long)blockIdx.y * CSV_ROWS;
-    long long r1 = r0 + CSV_ROWS;
+    const long long r0 = (long long)blockIdx.y * CSVF_ROWS;
+    long long r1 = r0 + CSVF_ROWS;
     if (r1 > rows) r1 = rows;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < cols) {
@@ -563,13 +573,13 @@ extern "C" int av_colsum(const void* x, int xdt, float* out, long long rows, int
     }
     if (rows == 0) return AV_OK;
     if (xdt == AV_BF16 && cols % 8 == 0 && ld % 8 == 0 && (uintptr_t)x % 16 == 0) {
-        dim3 gv((unsigned)((cols + 511) / 512), (unsigned)((rows + CSV_ROWS - 1) / CSV_ROWS));
+        dim3 gv((unsigned)((cols + CSVB_COLS - 1) / CSVB_COLS), (unsigned)((rows + CSV_ROWS - 1) / CSV_ROWS));
         hipLaunchKernelGGL(colsum_bf16_vec_kernel, gv, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, cols, ld);
         AV_LAUNCH_CHECK();
         return AV_OK;
     }
     if (xdt == AV_F32 && cols % 4 == 0 && ld % 4 == 0 && (uintptr_t)x % 16 == 0) {
-        dim3 gv((unsigned)((cols + 255) / 256), (unsigned)((rows + CSV_ROWS - 1) / CSV_ROWS));
+        dim3 gv((unsigned)((cols + 255) / 256), (unsigned)((rows + CSVF_ROWS - 1) / CSVF_ROWS));
         hipLaunchKernelGGL(colsum_f32_vec_kernel, gv, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, rows, cols, ld);
         AV_LAUNCH_CHECK();
         return AV_OK;
