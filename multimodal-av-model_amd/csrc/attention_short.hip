@@ -233,6 +233,7 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
     int klen = p.klen ? p.klen[b] : p.Tk;
     if (klen > p.Tk) klen = p.Tk;
     if (klen < 1) klen = 1;
+    klen = __builtin_amdgcn_readfirstlane(klen);                // wave-uniform: whole key tiles below klen skip the padding test
     const bf16_t* Q = (const bf16_t*)p.q + (long long)b * p.q_bs + (long long)h * 64;
     const bf16_t* K = (const bf16_t*)p.k + (long long)b * p.k_bs + (long long)h * 64;
     const bf16_t* V = (const bf16_t*)p.v + (long long)b * p.v_bs + (long long)h * 64;
@@ -274,32 +275,43 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
             a = mfma(row_frag(Ks, 16 * t + r, g), qf[i][0], a);
             a = mfma(row_frag(Ks, 16 * t + r, 4 + g), qf[i][1], a);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a[e] = (16 * t + 4 * g + e) < klen ? a[e] * c : -INFINITY;
-                mx = fmaxf(mx, a[e]);
-            }
             S[t] = a;
         }
+        // the kernel is bound by vector issue: the maximum is taken over the RAW scores (the scale is positive and folds into the
+        // exponent's FMA), and only key tiles that reach past klen pay the padding test (wave-uniform branches, kept out of the MFMA loop
+        // above so that its LDS reads and MFMAs stay one schedulable block)
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; ++t)
+            if (16 * t + 16 > klen) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[t][e] = (16 * t + 4 * g + e) < klen ? S[t][e] : -INFINITY;
+            }
+#pragma unroll
+        for (int t = 0; t < 2 * NKP; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, S[t][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmxc = -(mx * c);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2 * NKP; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(S[t][e] - mx);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][e], c, nmxc));      // exp2(-inf) = 0 for masked keys
                 sum += pv;
                 S[t][e] = pv;
             }
+        float ikf = 1.0f;                                       // DROP 2: 1 / (1 - p) multiplies the normalisation instead of every probability
         if (DROP) {
             const float ik = 1.0f / (1.0f - p.drop_p);
             if constexpr (DROP == 2) {
+                ikf = ik;
 #pragma unroll
                 for (int t = 0; t < 2 * NKP; ++t)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        S[t][e] = (((4 * t + e < 32 ? mb[i].x : mb[i].y) >> ((4 * t + e) & 31)) & 1u) ? S[t][e] * ik : 0.f;
+                        S[t][e] = (((4 * t + e < 32 ? mb[i].x : mb[i].y) >> ((4 * t + e) & 31)) & 1u) ? S[t][e] : 0.f;
             } else {
                 const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * ((p.Tk + 3) & ~3);
 #pragma unroll
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
             for (int n = 0; n < 4; ++n) O[n] = mfma(tr_frag(Vs, 32 * tp, n, lane), pf, O[n]);
         }
         if (qrow < p.Tq) {
-            const float inv = 1.0f / sum;
+            const float inv = ikf / sum;
             bf16_t* o = (bf16_t*)p.o + (long long)b * p.o_bs + (long long)qrow * p.o_rs + (long long)h * 64 + 4 * g;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
                 for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(O[n][e] * inv);
                 *(bf16x4*)(o + 16 * n) = ov;
             }
-            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Tq + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Tq + qrow] = (mx * c + __builtin_amdgcn_logf(sum)) * LN2;
         }
     }
 }
@@ -476,6 +488,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
     int klen = p.klen ? p.klen[b] : p.Tk;
     if (klen > p.Tk) klen = p.Tk;
     if (klen < 1) klen = 1;
+    klen = __builtin_amdgcn_readfirstlane(klen);
     const bf16_t* Q = p.q + (long long)b * p.q_bs + (long long)h * 64;
     const bf16_t* K = p.k + (long long)b * p.k_bs + (long long)h * 64;
     const bf16_t* V = p.v + (long long)b * p.v_bs + (long long)h * 64;
@@ -515,7 +528,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
             }
         }
     }
-    for (int i = tid; i < R; i += NT) lse_s[i] = i < p.Tq ? lse[i] * LOG2E : 0.f;
+    for (int i = tid; i < R; i += NT) lse_s[i] = i < p.Tq ? lse[i] * LOG2E : INFINITY;      // padded queries: exp2(s c - inf) = 0, no per-element test
     if constexpr (DROP == 2) {
         const uint2* gm = (const uint2*)p.dmask + (dbase_m << 6);
         for (int i = tid; i < nqt_m * 64; i += NT) mask_s[i] = gm[i];
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
         const long long kld = krow < p.Tk ? krow : p.Tk - 1;
         const bf16x8 kf0 = *(const bf16x8*)(K + kld * p.k_rs + 8 * g), kf1 = *(const bf16x8*)(K + kld * p.k_rs + 32 + 8 * g);
         const bf16x8 vf0 = *(const bf16x8*)(V + kld * p.v_rs + 8 * g), vf1 = *(const bf16x8*)(V + kld * p.v_rs + 32 + 8 * g);
-        const bool kok = krow < klen;
+        const float kneg = krow < klen ? 0.f : -INFINITY;           // padded / masked keys vanish in the exponent too
         f32x4 dVt[4], dKt[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { dVt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -563,11 +576,10 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int q = q0 + 4 * g + e;
-                    const float pv = (kok && q < p.Tq) ? __builtin_amdgcn_exp2f(s[e] * c - l4[e]) : 0.f;
+                for (int e = 0; e < 4; ++e) {                // vector issue bounds this kernel: one FMA into the exponent, the softmax scale
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, kneg - l4[e]));      // multiplies dK^T once at the end
                     Pt[hf][e] = pv * dm[e];
-                    St[hf][e] = pv * (dp[e] * dm[e] - d4[e]) * p.scale;
+                    St[hf][e] = pv * __builtin_fmaf(dp[e], dm[e], -d4[e]);
                 }
             }
             const bf16x8 pf = pack8(Pt[0], Pt[1]), sf = pack8(St[0], St[1]);
@@ -584,7 +596,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
             for (int n = 0; n < 4; ++n) {
                 bf16x4 a, c4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] = (bf16_t)dKt[n][e]; c4[e] = (bf16_t)dVt[n][e]; }
+                for (int e = 0; e < 4; ++e) { a[e] = (bf16_t)(dKt[n][e] * p.scale); c4[e] = (bf16_t)dVt[n][e]; }
                 *(bf16x4*)(ok + 16 * n) = a;
                 *(bf16x4*)(ov + 16 * n) = c4;
             }
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
         const bf16x8 qf0 = *(const bf16x8*)(Q + qld * p.q_rs + 8 * g), qf1 = *(const bf16x8*)(Q + qld * p.q_rs + 32 + 8 * g);
         const bf16x8 of0 = *(const bf16x8*)(DO + qld * p.do_rs + 8 * g), of1 = *(const bf16x8*)(DO + qld * p.do_rs + 32 + 8 * g);
         const bool qok = qrow < p.Tq;
-        const float lq = lse_s[qrow], dq_ = del_s[qrow];
+        const float lq = lse_s[qrow], dq_ = del_s[qrow];            // lq = +inf for a padded query
         const uint2 mb2 = DROP == 2 ? mask_s[(qt << 6) + lane] : make_uint2(0u, 0u);                   // my query's keep bits
         const unsigned long long mbits = ((unsigned long long)mb2.y << 32) | mb2.x;
         f32x4 dQt[4];
@@ -631,12 +643,15 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
                         drop_mult4(p.drop_seed, p.drop_stream, (dbase + qrow) * ((p.Tk + 3) & ~3) + (k0 + 4 * g), p.drop_p, ik, m4);
                     }
                 }
+                float pv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + 4 * g + e;
-                    const float pv = (qok && key < klen) ? __builtin_amdgcn_exp2f(s[e] * c - lq) : 0.f;
-                    St[hf][e] = pv * (dp[e] * m4[e] - dq_) * p.scale;
+                for (int e = 0; e < 4; ++e) pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -lq));
+                if (k0 + 16 > klen) {                           // wave-uniform: only key tiles that reach past klen pay the test
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[e] = (k0 + 4 * g + e) < klen ? pv[e] : 0.f;
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) St[hf][e] = pv[e] * __builtin_fmaf(dp[e], m4[e], -dq_);
             }
             const bf16x8 sf = pack8(St[0], St[1]);
 #pragma unroll
@@ -648,7 +663,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
             for (int n = 0; n < 4; ++n) {
                 bf16x4 a;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = (bf16_t)dQt[n][e];
+                for (int e = 0; e < 4; ++e) a[e] = (bf16_t)(dQt[n][e] * p.scale);
                 *(bf16x4*)(oq + 16 * n) = a;
             }
         }
