@@ -543,6 +543,8 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
         const bf16x8 kf0 = *(const bf16x8*)(K + kld * p.k_rs + 8 * g), kf1 = *(const bf16x8*)(K + kld * p.k_rs + 32 + 8 * g);
         const bf16x8 vf0 = *(const bf16x8*)(V + kld * p.v_rs + 8 * g), vf1 = *(const bf16x8*)(V + kld * p.v_rs + 32 + 8 * g);
         const float kneg = krow < klen ? 0.f : -INFINITY;           // padded / masked keys vanish in the exponent too
+        const int mask_bit = 4 * kt + (r & 3), mask_sh = mask_bit & 31;
+        const unsigned* mask_w = (const unsigned*)mask_s + (mask_bit >> 5);
         f32x4 dVt[4], dKt[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { dVt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -562,15 +564,12 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
                     if constexpr (DROP == 2) {
                         // forward layout: query tile q0 / 16, lane' = (r' = query % 16 = 4 g + e, g' = (key % 16) / 4 = r >> 2), bit 4 kt + (key & 3):
                         // my four queries are four consecutive 64-bit words
+                        // my key's bit (4 kt + key % 4: the same 32-bit half and shift for every query of the sweep) of four consecutive
+                        // 64-bit words: four 4-byte reads at an 8-byte stride and one bit-field extract each
                         const int qt_ = (q0 >> 4) < nqt_m ? (q0 >> 4) : nqt_m - 1;
-                        const uint4* mp = (const uint4*)(mask_s + ((qt_ << 6) + ((r >> 2) << 4) + 4 * g));
-                        const uint4 w01 = mp[0], w23 = mp[1];
-                        const int bit = 4 * kt + (r & 3);
-                        const bool lo = bit < 32;
-                        const int sh = bit & 31;
-                        const unsigned s0 = (lo ? w01.x : w01.y) >> sh, s1 = (lo ? w01.z : w01.w) >> sh;
-                        const unsigned s2 = (lo ? w23.x : w23.y) >> sh, s3 = (lo ? w23.z : w23.w) >> sh;
-                        dm[0] = (s0 & 1u) ? ik : 0.f; dm[1] = (s1 & 1u) ? ik : 0.f; dm[2] = (s2 & 1u) ? ik : 0.f; dm[3] = (s3 & 1u) ? ik : 0.f;
+                        const unsigned* mp = mask_w + 2 * ((qt_ << 6) + ((r >> 2) << 4) + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dm[e] = __builtin_amdgcn_ubfe(mp[2 * e], (unsigned)mask_sh, 1u) ? ik : 0.f;
                     } else {
                         drop_quad4(p.drop_seed, p.drop_stream, (dbase + q0 + 4 * g) * ((p.Tk + 3) & ~3), (unsigned long long)((p.Tk + 3) & ~3), krow, r, p.drop_p, ik, dm);
                     }
