@@ -120,6 +120,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python {os.path.join(_HERE, 'build.py')}` "
                 "(hipcc --offload-arch=gfx950). The MI355X path has no CPU/PyTorch fallback.")
+        # torch first: libavhip.so links against libamdhip64, and the process must end up with ONE HIP runtime - the one PyTorch-ROCm
+        # ships.  Loading this library before torch binds it to the system runtime instead; torch then shares that copy and kernels
+        # registered here fail later in odd ways (hipFuncSetAttribute: "cannot raise dynamic LDS" in build() + smoke() of one process).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)           # AttributeError if a declared symbol is not exported
