@@ -29,6 +29,7 @@ from ..utils.shadow import ParamCache
 Tensor = torch.Tensor
 # attention-dropout keep bits evaluated once per step on a side stream (0: every kernel generates its masks itself; A/B runs)
 DROP_BITS = os.environ.get("AVAMD_ATTN_DROPBITS", "1") != "0"
+DROP_BITS_ALL = os.environ.get("AVAMD_ATTN_DROPBITS_ALL", "0") != "0"
 # FFN activation site saves its gradient factor instead of the pre-activation (bf16 mode); AVAMD_FFN_GF=0 = recompute gelu' and the mask in the backward
 FFN_GF = os.environ.get("AVAMD_FFN_GF", "1") != "0"
 # the second audio pass of a step runs on its own stream beside the first (HBM-bound row kernels of one pass overlap MFMA-bound GEMMs of the other)
@@ -305,16 +306,22 @@ class Wav2Vec2ModelHIP(nn.Module):
         # Attention-dropout keep bits of the layers that get a backward: ONE generator evaluation per probability (instead of one in the
         # forward and two in the backward), on a side stream - the kernels depend on no data and are pure VALU work beside the GEMMs
         amasks, amask_evt = {}, None
+        bits_from = 0 if DROP_BITS_ALL else first               # AVAMD_ATTN_DROPBITS_ALL=1: keep bits also for the layers without a backward
         if at_p > 0 and save and first < nl and dev.type == "cuda" and DROP_BITS and ops.attention_mask_shape_ok(dtype, B, T, T, hd):
             if getattr(self, "_mask_stream", None) is None:
                 self._mask_stream = torch.cuda.Stream(device=dev)
             main = torch.cuda.current_stream(dev)
             self._mask_stream.wait_stream(main)
+            amask_evts = {}
             with torch.cuda.stream(self._mask_stream):
-                for li in range(first, nl):
+                for li in range(bits_from, nl):
                     if not dropped[li]:
                         amasks[li] = ops.attention_dropmask(B, nh, T, T, (at_p, seed, li * 8 + 3), dev)
-            amask_evt = torch.cuda.Event(); amask_evt.record(self._mask_stream)
+                        if li < first or li == nl - 1 or (li - first) % 6 == 5:           # layers without a backward come first and are
+                            amask_evts[li] = torch.cuda.Event()                          # waited for one by one, the rest in groups
+                            amask_evts[li].record(self._mask_stream)
+                last_evt = torch.cuda.Event(); last_evt.record(self._mask_stream)
+            amask_evt = (amask_evts, last_evt)
             for m in amasks.values():
                 m.record_stream(main)
         mid = torch.zeros_like(h) if nl >= 10 else None
@@ -334,8 +341,13 @@ class Wav2Vec2ModelHIP(nn.Module):
             qkv = ops.linear(x1, self.qkv_w(li, dtype), self.qkv_b(li), out_dtype=dtype).view(B, T, 3, nh, hd)
             amask = amasks.get(li)
             if amask is not None and amask_evt is not None:
-                torch.cuda.current_stream(dev).wait_event(amask_evt)
-                amask_evt = None
+                evts, last_evt = amask_evt
+                nxt = min((l for l in evts if l >= li), default=None)           # the first recorded event at or after this layer's mask
+                torch.cuda.current_stream(dev).wait_event(evts.pop(nxt) if nxt is not None else last_evt)
+                for l in [l for l in evts if l < li]:
+                    evts.pop(l)
+                if nxt is None:
+                    amask_evt = None
             ao, lse = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], klen, scale, need_lse=keep_ctx,
                                         drop=(at_p, seed, li * 8 + 3), drop_mask=amask)
             h2 = ops.linear(ao.view(B, T, Hd), self.c(p + "attention.out_proj.weight", dtype), self.P(p + "attention.out_proj.bias").data,
