@@ -125,6 +125,21 @@ def test_matmul_nn_tn(dtype, M, N, K):
     torch.testing.assert_close(acc, ref, **_tol(dtype))
 
 
+@pytest.mark.parametrize("K,M,N", [(4200, 2048, 1024), (12736, 1024, 1024), (3000, 1024, 4096), (6368, 3072, 1024)])
+def test_matmul_tn_large_split_k(K, M, N):
+    """dW-shaped products at the step's sizes (both operands k-major, K = tokens split over the batch: ragged last K slice, ragged last
+    K-tile, row-strided operand views, accumulation into an existing gradient)."""
+    a = _rand(K, M + 64, dtype=torch.bfloat16, scale=1.0)[:, 32:32 + M]                 # row-strided view, 16-byte aligned
+    b = _rand(K, N, dtype=torch.bfloat16, scale=1 / math.sqrt(K))
+    ref = _ref_mm(a.t(), b)
+    tol = dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(ops.matmul_tn(a, b), ref, **tol)
+    acc = _rand(M, N)
+    exp = acc + 0.5 * ref
+    ops.matmul_tn(a, b, out=acc, alpha=0.5, accumulate=True)
+    torch.testing.assert_close(acc, exp, **tol)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_batched_strided_gemm(dtype):
     """QK^T-style batched product with head-strided operands."""

@@ -16,7 +16,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) * 1000 / n
 
 
-T = 6368
+T = int(os.environ.get("TN_T", "12736"))
 for (Nout, Kin) in [(1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096)]:
     dy = (torch.rand(T, Nout, device="cuda") - 0.5).to(torch.bfloat16)
     x = (torch.rand(T, Kin, device="cuda") - 0.5).to(torch.bfloat16)
