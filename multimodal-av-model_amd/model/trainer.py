@@ -120,7 +120,7 @@ class MultimodalTrainer:
             # priority right after the fusion backward): start their all-reduce there, under the whole audio backward
             self._head_done = False
             if pair_batched:                                   # one fusion / decoder call per step: no later accumulation into these grads
-                self.audio_encoder.model.grad_pre = self._reduce_head
+                self.audio_encoder.model.grad_pre = self._reduce_head_early
 
     # ------------------------------------------------------------------------------------------------------------
     def _to_dev(self, batch):
@@ -263,7 +263,12 @@ class MultimodalTrainer:
                 main.wait_stream(self._vstream2)
             vf1.record_stream(main); vf2.record_stream(main)
         B = a1.shape[0]
-        if self.pair_batched:
+        # the two speakers go through fusion / decoder / CTC as one stacked call only if their lip clips were padded to the same length;
+        # the reference's collate pads lip1 and lip2 separately (dataset/collate_fn.py:8-13,27-31), so a real batch can differ - then one
+        # call per speaker, as the reference does (found by tests/test_dataset_gpu.py::test_dataset_feeds_the_training_step)
+        pair = self.pair_batched and vf1.shape[1] == vf2.shape[1]
+        self._pair_step = pair
+        if pair:
             f12, il12 = self.fusion_module(torch.cat([vf1, vf2], 0), torch.cat([a1, a2], 0), mask=torch.cat([m1, m2], 0), groups=2)
             lp12 = self.decoder1(f12)
             f1, f2, il1, il2, lp1, lp2 = f12[:B], f12[B:], il12[:B], il12[B:], lp12[:B], lp12[B:]
@@ -272,7 +277,7 @@ class MultimodalTrainer:
             f2, il2 = self.fusion_module(vf2, a2, mask=m2)
             lp1 = self.decoder1(f1)
             lp2 = self.decoder1(f2)
-        if self.pair_batched:
+        if pair:
             # one nn.functional.ctc_loss call (PyTorch-ROCm, as north_star prescribes) over the 2B items; 'mean' reduction
             # of nn.CTCLoss = mean_i(nll_i / clamp(target_len_i, 1)) is re-applied per speaker half
             t1, t2 = d["text1"], d["text2"]
@@ -318,6 +323,12 @@ class MultimodalTrainer:
         self.scaler.step(self.optimizer)                           # model/trainer.py:122-123 (update() is part of the device-side step)
         self.scaler.update()
         return out
+
+    def _reduce_head_early(self):
+        # hook at the start of the wav2vec2 backward: valid only when this step made ONE fusion / decoder call (a batch whose two lip
+        # clips were padded differently falls back to one call per speaker: its head bucket goes after the backward, in train_step)
+        if getattr(self, "_pair_step", True):
+            self._reduce_head()
 
     def _reduce_head(self):
         # once per step: with two audio passes the wav2vec2 backward (and this hook) runs twice, and p.grad are by then views of the
