@@ -134,6 +134,9 @@ def test_dataset_feeds_the_training_step(tmp_path):
     for batch in loader:
         assert batch["audio"].is_cuda and set(batch.keys()) >= {"lip1", "lip2", "text1", "text2", "audio", "mask1", "mask2", "audio_lengths"}
         out = t.train_step(batch)
-        losses.append(float(out["total"]))
+        losses.append(float(out["total"].detach()))
     assert len(losses) == 2 and all(np.isfinite(l) and l > 0 for l in losses)
     assert not torch.equal(before, t.decoder1.net[0].weight.detach())
+    ev_loss, wer = t.evaluate(loader)                                     # main.py:168 on the same loader: greedy decode + WER on the device
+    assert np.isfinite(ev_loss) and 0.0 <= wer
+    assert np.isfinite(t.train_epoch(loader))                             # main.py:165
