@@ -118,15 +118,16 @@ def test_dataset_iteration_and_errors(tmp_path):
         d.load_pair(sents[1], bad)
 
 
-def test_dataset_feeds_the_training_step(tmp_path):
+@pytest.mark.parametrize("bs,precision", [(2, "fp32"), (1, "bf16"), (3, "bf16")])
+def test_dataset_feeds_the_training_step(tmp_path, bs, precision):
     """files -> FixedSentencePairDataset -> torch DataLoader (collate_fn, no workers) -> MultimodalTrainer.train_step: the callers on the input
     side of the hot path and the path itself in one loop, as main.py:88-129 wires them (tiny wav2vec2 configuration, fp32 mode)."""
     from test_step_gpu import build as build_trainer
     ds = pkg("dataset.multi_speaker_dataset"); cf = pkg("dataset.collate_fn").collate_fn; init = pkg("utils.init")
     _, sents = _make_corpus(tmp_path)
     pairs = [(sents[0], sents[2]), (sents[1], sents[3]), (sents[2], sents[1]), (sents[3], sents[0])]
-    loader = torch.utils.data.DataLoader(ds.FixedSentencePairDataset(pairs, _Tok()), batch_size=2, shuffle=False, collate_fn=cf, num_workers=0)
-    t = build_trainer(init.W2V2_TINY, "fp32")
+    loader = torch.utils.data.DataLoader(ds.FixedSentencePairDataset(pairs, _Tok()), batch_size=bs, shuffle=False, collate_fn=cf, num_workers=0)
+    t = build_trainer(init.W2V2_TINY, precision)
     for m in (t.visual_encoder, t.audio_encoder, t.fusion_module, t.decoder1):
         m.train()
     before = t.decoder1.net[0].weight.detach().clone()
@@ -135,7 +136,7 @@ def test_dataset_feeds_the_training_step(tmp_path):
         assert batch["audio"].is_cuda and set(batch.keys()) >= {"lip1", "lip2", "text1", "text2", "audio", "mask1", "mask2", "audio_lengths"}
         out = t.train_step(batch)
         losses.append(float(out["total"].detach()))
-    assert len(losses) == 2 and all(np.isfinite(l) and l > 0 for l in losses)
+    assert len(losses) == (4 + bs - 1) // bs and all(np.isfinite(l) and l > 0 for l in losses)
     assert not torch.equal(before, t.decoder1.net[0].weight.detach())
     ev_loss, wer = t.evaluate(loader)                                     # main.py:168 on the same loader: greedy decode + WER on the device
     assert np.isfinite(ev_loss) and 0.0 <= wer
