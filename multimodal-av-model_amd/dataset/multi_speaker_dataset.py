@@ -175,6 +175,9 @@ class MultiSpeakerDataset(torch.utils.data.Dataset):
         return t
 
     def load_pair(self, s1, s2):
+        if torch.utils.data.get_worker_info() is not None:
+            raise RuntimeError("this dataset keeps its data on the GPU and must run in the training process: DataLoader(..., num_workers=0, "
+                               "pin_memory=False) (the reference's worker processes only hid host decoding, main.py:88)")
         a1, a2 = self._clip(s1), self._clip(s2)
         out = dp.mix_pair(a1, a2)                                               # :21-45 on the device
         try:
