@@ -136,3 +136,22 @@ def test_two_rank_regularized_two_pass_steps_stay_in_lockstep(tmp_path):
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k
     assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (the driver's scaling runs): it must start two fresh ranks itself, run both
+    variants under the gradient reducer and relay rank 0's ONE JSON line.  Two ranks share this box's one GPU over gloo (the RCCL
+    transport needs one GPU per rank); small batch, 1 s clips."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "2",
+                        "--warmup", "1", "--batch", "4", "--seconds", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["config"]["audio_passes"] == 2
+    assert d["value"] > 0 and np.isfinite(d["config"]["final_loss"]) and d["other_variant"]["audio_passes"] == 1
