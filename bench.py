@@ -82,6 +82,37 @@ NO_REGULARIZERS = dict(hidden_dropout=0.0, attention_dropout=0.0, activation_dro
                        mask_time_prob=0.0)
 
 
+def build_trainer(batch_size, seconds, precision, dev, rank=0, reducer=None, lambda_=0.1, no_pair=False, no_side_stream=False,
+                  loss_scaling=False):
+    """The benchmark's model (wav2vec2-large + ResNet-18 lip encoder + fusion + CTC head, seeded random weights, the reference's freeze
+    policy main.py:26-31,100-106), its trainer and one HBM-resident synthetic batch with the host-side metadata merged in."""
+    init = imp("utils.init"); synth = imp("dataset.synthetic"); enc = imp("model.encoder"); fm = imp("model.fusion_module")
+    dm = imp("model.decoder"); tr = imp("model.trainer"); tok = imp("utils.tokenizer")
+    imp("precision").set_precision(precision)
+    cfg = dict(init.W2V2_LARGE)
+    ve = enc.VisualEncoder(); ve.load_state_dict(init.visual_state_dict())
+    for p in ve.parameters():
+        p.requires_grad = False
+    ae = enc.AudioEncoder(dict(cfg), freeze=True)
+    for n, p in ae.model.named_parameters():
+        p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
+    fu = fm.CrossAttentionFusion(512, cfg["hidden_size"], 512); fu.load_state_dict(init.fusion_state_dict(512, cfg["hidden_size"], 512))
+    de = dm.CTCDecoder(1024, 800, 3); de.load_state_dict(init.decoder_state_dict(1024, 800))
+    t = tr.MultimodalTrainer(ve, ae, fu, de, tok.SyntheticTokenizer(800), learning_rate=1e-4, device=dev, lambda_=lambda_,
+                             audio_passes=None, reducer=reducer, pair_batched=not no_pair, visual_side_stream=not no_side_stream,
+                             loss_scaling=loss_scaling)
+    if no_side_stream:
+        imp("model.w2v2").PASS_STREAMS = False
+    t.fixed_projection = init.projection_params(cfg["hidden_size"])      # identical on every rank (SURVEY §8e caveat 4)
+    t.visual_encoder.train(); t.audio_encoder.train(); t.fusion_module.train(); t.decoder1.train()
+    cpu_batch = synth.make_batch(batch_size, seconds, seed=42 + rank)
+    T_enc = int(imp("model.w2v2").conv_out_lengths(cfg, cpu_batch["audio"].shape[1]))
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+    batch.update(t.host_metadata(cpu_batch, T_enc))        # class counts + CTC lengths from the host copy: no device read-back in the step
+    batch.update(_T_audio=cpu_batch["audio"].shape[1], _T_v=cpu_batch["lip1"].shape[1], _T_enc=T_enc)
+    return t, batch, cfg
+
+
 def spawn_ranks(n: int) -> int:
     """``python bench.py --gpus N`` as typed: this process has not touched the GPU yet, so it starts N fresh ranks under
     torch.distributed.run (one per GPU, RCCL), relays their output and returns their exit code."""
@@ -137,6 +168,7 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="build the process group and the gradient reducer even with one rank (RCCL path rehearsal)")
     ap.add_argument("--no-side-stream", action="store_true", help="one stream: visual encoder and second audio pass on the main stream (no overlap; profiling)")
     ap.add_argument("--no-pair", action="store_true", help="one fusion/decoder call per speaker, as the reference does")
+    ap.add_argument("--loss-scaling", action="store_true", help="GradScaler law of the reference's GPU mode (model/trainer.py:40,121-123): BASELINE configs[4]")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -162,35 +194,13 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    init = imp("utils.init"); synth = imp("dataset.synthetic"); enc = imp("model.encoder"); fm = imp("model.fusion_module")
-    dm = imp("model.decoder"); tr = imp("model.trainer"); tok = imp("utils.tokenizer"); dp = imp("parallel.dp"); ops = imp("ops")
-    L = imp("_lib")
-    imp("precision").set_precision(args.precision)
-    cfg = dict(init.W2V2_LARGE)
-
-    ve = enc.VisualEncoder(); ve.load_state_dict(init.visual_state_dict())
-    for p in ve.parameters():
-        p.requires_grad = False
-    ae = enc.AudioEncoder(dict(cfg), freeze=True)
-    for n, p in ae.model.named_parameters():
-        p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
-    fu = fm.CrossAttentionFusion(512, cfg["hidden_size"], 512); fu.load_state_dict(init.fusion_state_dict(512, cfg["hidden_size"], 512))
-    de = dm.CTCDecoder(1024, 800, 3); de.load_state_dict(init.decoder_state_dict(1024, 800))
+    ops = imp("ops"); L = imp("_lib")
+    dp = imp("parallel.dp")
     reducer = dp.GradBucketReducer(always_collective=args.force_dp) if (world > 1 or args.force_dp) else None
-    t = tr.MultimodalTrainer(ve, ae, fu, de, tok.SyntheticTokenizer(800), learning_rate=1e-4, device=dev, lambda_=args.lambda_,
-                             audio_passes=None, reducer=reducer, pair_batched=not args.no_pair,
-                             visual_side_stream=not args.no_side_stream)
-    if args.no_side_stream:
-        imp("model.w2v2").PASS_STREAMS = False
-    t.fixed_projection = init.projection_params(cfg["hidden_size"])      # identical on every rank (SURVEY §8e caveat 4)
-    t.visual_encoder.train(); t.audio_encoder.train(); t.fusion_module.train(); t.decoder1.train()
-
-    cpu_batch = synth.make_batch(args.batch, args.seconds, seed=42 + rank)
-    T_audio = cpu_batch["audio"].shape[1]
-    T_v = cpu_batch["lip1"].shape[1]
-    T_enc = int(imp("model.w2v2").conv_out_lengths(cfg, T_audio))
-    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
-    batch.update(t.host_metadata(cpu_batch, T_enc))        # class counts + CTC lengths from the host copy: no device read-back in the step
+    t, batch, cfg = build_trainer(args.batch, args.seconds, args.precision, dev, rank=rank, reducer=reducer, lambda_=args.lambda_,
+                                  no_pair=args.no_pair, no_side_stream=args.no_side_stream, loss_scaling=args.loss_scaling)
+    ae = t.audio_encoder
+    T_audio, T_v, T_enc = batch["_T_audio"], batch["_T_v"], batch["_T_enc"]
 
     def barrier():
         if world > 1:

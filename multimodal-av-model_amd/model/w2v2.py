@@ -138,6 +138,10 @@ class Wav2Vec2ModelHIP(nn.Module):
         # ranks that disagreed would issue different collective sequences) and a dropout-seed generator that DIFFERS per rank
         self.layerdrop_generator = None
         self.dropout_generator = None
+        # bookkeeping of the LayerDrop draws: encoder layers executed forward / with a backward / with weight gradients since the last reset
+        # (all passes), and optionally the list of dropped layers per pass (diagnostics, tests)
+        self.layers_executed = self.layers_executed_bwd = self.layers_executed_bwd_tr = 0
+        self.dropped_log = None
 
     # ---- parameter access ------------------------------------------------------------------------------------
     def P(self, name: str) -> Tensor:
@@ -303,6 +307,12 @@ class Wav2Vec2ModelHIP(nn.Module):
         first = train.index(True) if any(train) else nl
         # LayerDrop decisions (hf:774-789), drawn up front in layer order (the same draws the loop would make)
         dropped = [bool(ld_p > 0 and float(torch.rand([], generator=self.layerdrop_generator)) < ld_p) for _ in range(nl)]
+        self.layers_executed += nl - sum(dropped)                  # executed (not expected) work: bench.py's FLOP accounting
+        if save:
+            self.layers_executed_bwd += sum(1 for li in range(first, nl) if not dropped[li])
+            self.layers_executed_bwd_tr += sum(1 for li in range(first, nl) if not dropped[li] and train[li])
+        if self.dropped_log is not None:
+            self.dropped_log.append([li for li, d in enumerate(dropped) if d])
         # Attention-dropout keep bits of the layers that get a backward: ONE generator evaluation per probability (instead of one in the
         # forward and two in the backward), on a side stream - the kernels depend on no data and are pure VALU work beside the GEMMs
         amasks, amask_evt = {}, None
