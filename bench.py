@@ -16,6 +16,7 @@ from __future__ import annotations
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -32,8 +33,10 @@ def imp(sub):
     return importlib.import_module(PKG + "." + sub)
 
 
-def flops_per_utt(cfg, T_audio, T_v, audio_passes):
-    """SURVEY §8(d) algorithmic FLOPs (2*MAC) per utterance, fwd + needed bwd, for the variant executed."""
+def flops_per_utt(cfg, T_audio, T_v, audio_passes, layers=None):
+    """SURVEY §8(d) algorithmic FLOPs (2*MAC) per utterance, fwd + needed bwd, for the variant executed.  ``layers`` = encoder layers
+    actually executed per step, summed over the audio passes: (forward, backward without weight gradients, backward with weight
+    gradients) - counted by the model from its LayerDrop draws (hf:774-789); None = no layer dropped."""
     L = T_audio
     conv = 0.0
     cin = 1
@@ -46,13 +49,16 @@ def flops_per_utt(cfg, T_audio, T_v, audio_passes):
     lin = (8.0 * H * H + 4.0 * H * I) * T
     att = 4.0 * T * T * H
     kp, G = cfg["num_conv_pos_embeddings"], cfg["num_conv_pos_embedding_groups"]
-    A = conv + 2.0 * cin * H * T + 2.0 * kp * (H // G) * H * T + nl * (lin + att)
-    Ab = 14 * (lin + 2 * att) + 4 * (2 * lin + 2 * att)
+    if layers is None:
+        layers = (audio_passes * nl, audio_passes * 14, audio_passes * 4)
+    n_f, n_b, n_bt = layers
+    A0 = conv + 2.0 * cin * H * T + 2.0 * kp * (H // G) * H * T          # feature extractor + projection + positional conv
+    enc = n_f * (lin + att) + n_b * (lin + 2 * att) + n_bt * (2 * lin + 2 * att)
     V = 695.2e6 * T_v
     F = T_v * (2 * 512 ** 2 + 2 * 1024 * 512 + 8 * 512 ** 2 + 2 * 512 ** 2 + 2 * 4 * 512 * (1024 + 1536) * 2 + 2 * 1024 * 800) + 4.0 * T_v ** 2 * 512
     # with two audio passes the frozen, dropout-free conv feature extractor runs ONCE (model/trainer.py: shared between the passes):
     # count what is executed
-    return audio_passes * (A + Ab) - (audio_passes - 1) * conv + 2 * V + 2 * F + 2 * 2 * F
+    return audio_passes * A0 - (audio_passes - 1) * conv + enc + 2 * V + 2 * F + 2 * 2 * F
 
 
 def cpu_baseline(cfg, seconds):
@@ -212,16 +218,40 @@ def main():
         ae.model.cfg.update(HF_REGULARIZERS if v == "as_executed" else NO_REGULARIZERS)
         return 2 if v == "as_executed" else 1
 
+    # Every leg (headline, other variant, roofline probe) starts from the SAME state: initial weights, BatchNorm running statistics, fresh
+    # optimizer / scaler state.  No leg runs on the weights another leg left behind.
+    state_tensors = [p for m in (t.audio_encoder, t.fusion_module, t.decoder1) for p in m.parameters() if p.requires_grad]
+    state_tensors += [b for b in t.visual_encoder.buffers()]
+    snap = [x.detach().clone() for x in state_tensors]
+
+    def restore():
+        with torch.no_grad():
+            for x, s0 in zip(state_tensors, snap):
+                x.copy_(s0)                                       # bumps the version counters: compute-dtype caches rebuild
+        t.optimizer.reset_state()
+        t.scaler = imp("optim").AvGradScaler(device=dev, enabled=args.loss_scaling)
+        t.projection_layer = None
+
+    def finite_state(loss_value):
+        """A leg is a measurement only if it ends with a finite loss AND finite weights (one reduction per trainable tensor, once per leg)."""
+        if not math.isfinite(loss_value):
+            return False
+        sums = torch.stack([p.detach().float().sum() for p in state_tensors])
+        return bool(torch.isfinite(sums).all())
+
     def timed(v):
+        restore()
         passes = set_variant(v)
         torch.manual_seed(1234 + rank)
         import numpy as np
         np.random.seed(1234 + rank)
+        m = ae.model
         for _ in range(args.warmup):
             out = t.train_step(batch)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        m.layers_executed = m.layers_executed_bwd = m.layers_executed_bwd_tr = 0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = t.train_step(batch)
@@ -234,18 +264,41 @@ def main():
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt)
-        return dt, passes, float(out["total"].detach())
+        lay = (m.layers_executed / args.steps, (m.layers_executed_bwd - m.layers_executed_bwd_tr) / args.steps, m.layers_executed_bwd_tr / args.steps)
+        loss_v = float(out["total"].detach())
+        return dict(dt=dt, passes=passes, loss=loss_v, layers=lay, valid=finite_state(loss_v), variant=v,
+                    scale=(t.scaler.get_scale(), t.scaler.steps_taken()) if args.loss_scaling else None)
+
+    def diverged(leg):
+        if rank == 0:
+            print(json.dumps({"metric": "utterances/sec (4 s clip, 25 fps 96x96 lip) at batch 64, full training step", "value": None,
+                              "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "valid": False,
+                              "status": "diverged", "config": {"variant": leg["variant"], "final_loss": None if not math.isfinite(leg["loss"]) else leg["loss"],
+                                                               "note": "non-finite loss or weights at the end of the timed region: not a measurement"}}),
+                  flush=True)
+        if world > 1 or args.force_dp:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        raise SystemExit(3)
 
     other = "deterministic" if args.variant == "as_executed" else "as_executed"
-    dt, passes, loss = timed(args.variant)
+    head_leg = timed(args.variant)
+    if not head_leg["valid"]:
+        diverged(head_leg)
     second = None if args.single_variant else timed(other)
-    set_variant(args.variant)
-    # roofline leg: the SAME workload for a few more steps with per-launch events around the dominant kernel and the attention
-    # launches.  The side streams (visual encoder, second audio pass) are switched off here so that the events bracket only the kernel
-    # (with several streams the elapsed time between events includes the other streams' kernels); this is what rocprofv3 reports as
-    # the duration of a kernel that runs alone.
+    if second is not None and not second["valid"]:
+        diverged(second)
+    # roofline leg: the SAME workload (same initial state, same seeds) for a few steps with per-launch events around the dominant kernel
+    # and the attention launches.  The side streams (visual encoder, second audio pass) are switched off here so that the events bracket
+    # only the kernel (with several streams the elapsed time between events includes the other streams' kernels); this is what
+    # rocprofv3 reports as the duration of a kernel that runs alone.
     probe = attn = None
     if not args.no_probe and rank == 0 and world == 1:
+        restore()
+        set_variant(args.variant)
+        torch.manual_seed(1234 + rank)
+        import numpy as np
+        np.random.seed(1234 + rank)
         t.visual_side_stream = False
         imp("model.w2v2").PASS_STREAMS = False                 # probe leg: one stream, so that the events bracket exactly one kernel
         t.train_step(batch)
@@ -254,10 +307,11 @@ def main():
         ops.AttnProbe.start()
         probe_steps = min(3, args.steps)
         for _ in range(probe_steps):
-            t.train_step(batch)
+            pout = t.train_step(batch)
         torch.cuda.synchronize()
         probe = ops.GemmProbe.stop()
         probe["steps"] = probe_steps
+        probe["valid"] = finite_state(float(pout["total"].detach()))
         if os.environ.get("AVAMD_PROBE_SHAPES"):                # per-shape table of the probed family (tools / DESIGN only)
             agg = {}
             for r in probe["records"]:
@@ -268,29 +322,33 @@ def main():
                 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     f.write(" ".join(str(int(x)) for x in k) + f" | {a[0] / probe_steps:6.1f} {1000 * a[1] / a[0]:8.1f} {a[2] / a[1] / 1e9:7.1f} {a[1] / probe_steps:7.2f}\n")
         attn = attention_report(ops.AttnProbe.stop(), probe_steps)
+        if not probe["valid"]:
+            diverged(dict(variant=args.variant + " (roofline probe leg)", loss=float(pout["total"].detach())))
 
     if rank == 0:
-        def line(dt_, passes_, variant):
-            fl = flops_per_utt(cfg, T_audio, T_v, passes_)
-            if variant == "as_executed":       # LayerDrop skips a layer (forward and backward) with probability 0.1: expected executed work
-                Hh, Ii = cfg["hidden_size"], cfg["intermediate_size"]
-                lin = (8.0 * Hh * Hh + 4.0 * Hh * Ii) * T_enc; att = 4.0 * T_enc * T_enc * Hh
-                ld = HF_REGULARIZERS["layerdrop"]
-                fl -= passes_ * ld * (24 * (lin + att) + 14 * (lin + 2 * att) + 4 * (2 * lin + 2 * att))
-            utt = args.batch * world / (dt_ / args.steps)
-            return {"value": round(utt, 3), "ms_per_step": round(1000.0 * dt_ / args.steps, 3), "audio_passes": passes_,
-                    "wav2vec2_regularizers": "hf-defaults (dropout 0.1, LayerDrop 0.1, SpecAugment 0.05)" if variant == "as_executed" else "off (deterministic parity configuration)",
-                    "algorithmic_gflop_per_utt": round(fl / 1e9, 1), "step_tflops": round(fl * utt / 1e12, 1),
-                    "step_frac_of_mfma_peak": round(fl * utt / 1e12 / peak, 4)}
+        def line(leg):
+            fl = flops_per_utt(cfg, T_audio, T_v, leg["passes"], leg["layers"])      # executed layers (LayerDrop draws are on the host), not expected ones
+            utt = args.batch * world / (leg["dt"] / args.steps)
+            out = {"value": round(utt, 3), "ms_per_step": round(1000.0 * leg["dt"] / args.steps, 3), "audio_passes": leg["passes"],
+                   "wav2vec2_regularizers": "hf-defaults (dropout 0.1, LayerDrop 0.1, SpecAugment 0.05)" if leg["variant"] == "as_executed" else "off (deterministic parity configuration)",
+                   "final_loss": round(leg["loss"], 4), "valid": leg["valid"],
+                   "encoder_layers_executed_per_step": {"forward": round(leg["layers"][0], 2), "backward_dx_only": round(leg["layers"][1], 2),
+                                                        "backward_dx_dw": round(leg["layers"][2], 2)},
+                   "algorithmic_gflop_per_utt": round(fl / 1e9, 1), "step_tflops": round(fl * utt / 1e12, 1),
+                   "step_frac_of_mfma_peak": round(fl * utt / 1e12 / peak, 4)}
+            if leg["scale"] is not None:
+                out["loss_scaling"] = {"law": "torch.amp.GradScaler (init 65536, x2 / 2000 clean steps, x0.5 on overflow, overflowing steps skipped)",
+                                       "final_scale": leg["scale"][0], "optimizer_steps_taken": leg["scale"][1]}
+            return out
         peak = 2500.0 if args.precision == "bf16" else 157.3
-        head = line(dt, passes, args.variant)
+        head = line(head_leg)
         roof = None
         if probe and probe["records"]:
             tot_ms = sum(r[0].elapsed_time(r[1]) for r in probe["records"])
             tot_fl = sum(r[2] for r in probe["records"])
             tot_by = sum(r[3] for r in probe["records"])
             traffic = tsrc = None
-            for cand in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):       # separate rocprofv3 --pmc passes (see file)
+            for cand in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):       # separate rocprofv3 --pmc passes (see file)
                 pmc = os.path.join(ROOT, "profiles", cand)
                 if args.precision == "bf16" and os.path.exists(pmc):
                     tb = tl = 0                                                         # launch-weighted over the tilings of the family
@@ -305,7 +363,7 @@ def main():
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_note": f"HBM-side bytes per launch from profiles/{tsrc} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                     "algorithmic_bytes_per_launch": round(tot_by / n),
-                    "launches_per_step": n // probe["steps"], "measured": "same workload, extra steps after the timed region, single stream", "avg_launch_us": round(1000.0 * tot_ms / n, 2),
+                    "launches_per_step": n // probe["steps"], "measured": "same workload from the same initial state and seeds, separate leg after the timed region, single stream", "avg_launch_us": round(1000.0 * tot_ms / n, 2),
                     "algorithmic_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
         res = {"metric": "utterances/sec (4 s clip, 25 fps 96x96 lip) at batch 64, full training step", "value": head["value"],
                "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
@@ -315,12 +373,14 @@ def main():
                                       "BiLSTM + CTC + contrastive, fwd+bwd+Adam, random-init weights",
                           "variant": args.variant, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                           "audio_passes": head["audio_passes"], "wav2vec2_regularizers": head["wav2vec2_regularizers"],
-                          "lambda_contrastive": args.lambda_, "final_loss": round(loss, 4),
+                          "lambda_contrastive": args.lambda_, "final_loss": head["final_loss"],
+                          "encoder_layers_executed_per_step": head["encoder_layers_executed_per_step"],
+                          "loss_scaling": head.get("loss_scaling"),
                           "algorithmic_gflop_per_utt": head["algorithmic_gflop_per_utt"],
                           "step_tflops": head["step_tflops"], "step_frac_of_mfma_peak": head["step_frac_of_mfma_peak"]},
-               "roofline": roof}
+               "valid": True, "roofline": roof}
         if second is not None:
-            res["other_variant"] = dict(line(second[0], second[1], other), variant=other, steps=args.steps, warmup=args.warmup)
+            res["other_variant"] = dict(line(second), variant=other, steps=args.steps, warmup=args.warmup)
         if attn is not None:
             res["attention"] = attn
         if world == 1 and not args.no_cpu_baseline:

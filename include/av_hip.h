@@ -267,19 +267,19 @@ int av_mix_pair(const float* a1, long long len1, const float* a2, long long len2
                 unsigned* peak_ws, void* stream);
 int av_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, void* stream);
-/* multi-tensor form (one launch per step): ptrs [n_tensors][5] device pointers {param, grad, exp_avg, exp_avg_sq, shadow};
- * shadow = optional (0 = none) bf16 copy of the updated parameter, same element order (the perf path's cached compute-dtype
- * weight); chunk c = elements [chunk_start[c], +chunk_elems) of tensor chunk_tensor[c]; all arrays live on the device */
-int av_adam_multi(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
-                  int n_chunks, int chunk_elems, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
-/* the same step under loss scaling (replaces torch.amp.GradScaler.step + .update, model/trainer.py:40,121-123 of the reference;
- * torch/amp/grad_scaler.py:126-129 defaults): scaler_state = 5 device floats {scale, 1/scale, found_inf, growth tracker, steps taken}.
- * Three launches, no host synchronisation: non-finite check over every gradient -> Adam with grad * grad_scale / scale, skipped when
- * found_inf, bias corrections from the device-side step count -> scale update (x backoff on overflow, x growth after
- * growth_interval clean steps) */
-int av_adam_multi_scaled(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
-                         int n_chunks, int chunk_elems, float beta1, float beta2, float eps, float grad_scale, float* scaler_state,
-                         float growth, float backoff, int growth_interval, void* stream);
+/* multi-tensor form (every optimizer step of the trainer): ptrs [n_tensors][5] device pointers {param, grad, exp_avg, exp_avg_sq,
+ * shadow}; shadow = optional (0 = none) bf16 copy of the updated parameter, same element order (the perf path's cached compute-dtype
+ * weight); hyper [n_tensors][4] floats {lr, beta1, beta2, eps} (torch.optim.Adam param-group values, model/trainer.py:34-39); chunk c =
+ * elements [chunk_start[c], +chunk_elems) of tensor chunk_tensor[c]; steps = device int32 table of PER-TENSOR step counts
+ * (torch.optim.Adam's state[p]['step']: a parameter without a gradient in some step - LayerDrop - falls behind the others), tensor t
+ * owns steps[step_slot[t]]: read for the bias corrections, incremented by a trailing one-block launch.  All arrays live on the device.
+ * scaler_state != NULL = the same step under loss scaling (replaces torch.amp.GradScaler.step + .update, model/trainer.py:40,121-123
+ * of the reference; torch/amp/grad_scaler.py:126-129 defaults): 5 device floats {scale, 1/scale, found_inf, growth tracker, steps
+ * taken}; non-finite check over every gradient -> Adam with grad * grad_scale / scale, skipped (no counter advances) when found_inf
+ * -> scale update (x backoff on overflow, x growth after growth_interval clean steps).  No host synchronisation in either form */
+int av_adam_multi(const void* ptrs, const long long* sizes, const float* hyper, const int* chunk_tensor, const long long* chunk_start,
+                  int n_chunks, int chunk_elems, int* steps, const int* step_slot, int n_tensors, float grad_scale,
+                  float* scaler_state, float growth, float backoff, int growth_interval, void* stream);
 
 /* ---- legacy mel + GRU model (reference: "이전 버전/multimodal_ctc_korean.py":8-55, train loop
  * "이전 버전/train_ctc_korea.py":82-109).  Its convolutions (nn.Conv2d 3x3, :12,15) and all input / weight-gradient products run on

@@ -93,8 +93,7 @@ SIGNATURES = {
     "av_ctc_greedy": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "av_lip_gray_resize": [vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp],
     "av_mix_pair": [vp, ll, vp, ll, vp, vp, vp, vp, vp],
-    "av_adam_multi": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, f32, vp],
-    "av_adam_multi_scaled": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, f32, f32, i32, vp],
+    "av_adam_multi": [vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, f32, vp, f32, f32, i32, vp],
     "av_adam_step": [vp, vp, vp, vp, ll, f32, f32, f32, f32, i32, f32, vp],
     "av_softmax_bwd_rows": [vp, i32, vp, vp, i32, ll, i32, f32, i32, vp],
     "av_nchw_to_nhwc": [vp, vp, i32, ll, i32, i32, i32, i32, vp],

@@ -44,6 +44,5 @@ def load_checkpoint(trainer, path: str, *, audio_encoder: bool = False, optimize
         trainer.optimizer.load_state_dict(ck["optimizer"])
         sc = getattr(trainer, "scaler", None)
         if sc is not None and sc.enabled and "scaler" in ck:
-            sc.load_state_dict(ck["scaler"])
-            trainer.optimizer._scaler_seeded = None              # re-seed the device-side step count from the restored optimizer state
+            sc.load_state_dict(ck["scaler"])                     # (AvAdam.load_state_dict re-seeds the device-side per-parameter step table)
     return int(ck["epoch"]) + 1

@@ -162,36 +162,29 @@ __global__ __launch_bounds__(256) void grad_check_multi_kernel(const unsigned lo
     if (__any(bad) && (threadIdx.x & 63) == 0) gs[GS_INF] = 1.0f;          // every writer stores the same value
 }
 
-// torch/amp/grad_scaler.py:update (_amp_update_scale_): found_inf -> scale *= backoff, tracker = 0; otherwise tracker += 1 and
-// scale *= growth when it reaches the interval.  Also counts the optimizer steps that were not skipped and clears found_inf.
-__global__ void grad_scaler_update_kernel(float* __restrict__ gs, float growth, float backoff, int interval) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (gs[GS_INF] != 0.f) {
-        gs[GS_SCALE] *= backoff;
-        gs[GS_TRACK] = 0.f;
-    } else {
-        gs[GS_STEP] += 1.f;
-        const float tr = gs[GS_TRACK] + 1.f;
-        if (tr >= (float)interval) { gs[GS_SCALE] *= growth; gs[GS_TRACK] = 0.f; }
-        else gs[GS_TRACK] = tr;
-    }
-    gs[GS_INV] = 1.0f / gs[GS_SCALE];
-    gs[GS_INF] = 0.f;
-}
+// torch/amp/grad_scaler.py:update (_amp_update_scale_) is applied by adam_finish_kernel below: found_inf -> scale *= backoff, tracker = 0;
+// otherwise tracker += 1 and scale *= growth when it reaches the interval; it also counts the optimizer steps that were not skipped.
 
+// Per-tensor step counts live on the device (int32 table; tensor t of a launch owns slot step_slot[t]): a parameter that received no
+// gradient in some step (LayerDrop skipped its layer in both passes: torch.optim.Adam leaves its state['step'] behind) keeps its own bias
+// corrections, every step goes through THIS kernel, and under loss scaling a skipped (overflowing) step advances no counter - all without
+// the host knowing.  hyper[t] = {lr, beta1, beta2, eps}.  Bias corrections in double (1 - beta2^step loses half its digits in fp32).
 __global__ __launch_bounds__(256) void adam_multi_kernel(const unsigned long long* __restrict__ ptrs, const long long* __restrict__ sizes,
-                                                         const float* __restrict__ lrs, const int* __restrict__ chunk_tensor,
-                                                         const long long* __restrict__ chunk_start, int chunk_elems, float b1, float b2,
-                                                         float eps, float bc1, float bc2_sqrt, float gscale, const float* __restrict__ gs) {
-    if (gs) {                                                    // loss scaling: skip on overflow, unscale, step count from the device
+                                                         const f32x4* __restrict__ hyper, const int* __restrict__ chunk_tensor,
+                                                         const long long* __restrict__ chunk_start, int chunk_elems,
+                                                         const int* __restrict__ steps, const int* __restrict__ step_slot, float gscale,
+                                                         const float* __restrict__ gs) {
+    if (gs) {                                                    // loss scaling: skip on overflow, unscale
         if (gs[GS_INF] != 0.f) return;
         gscale *= gs[GS_INV];
-        const float step = gs[GS_STEP] + 1.f;
-        bc1 = 1.f - powf(b1, step);
-        bc2_sqrt = sqrtf(1.f - powf(b2, step));
     }
     const int c = blockIdx.x;
     const int t = chunk_tensor[c];
+    const f32x4 hp = hyper[t];
+    const float b1 = hp[1], b2 = hp[2], eps = hp[3];
+    const double step = (double)(steps[step_slot[t]] + 1);
+    const float bc1 = (float)(1.0 - pow((double)b1, step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
     float* p = (float*)ptrs[5 * t + 0];
     const float* g = (const float*)ptrs[5 * t + 1];
     float* m = (float*)ptrs[5 * t + 2];
@@ -201,7 +194,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const unsigned long lon
     const long long s0 = chunk_start[c];
     long long s1 = s0 + chunk_elems;
     if (s1 > n) s1 = n;
-    const float step_size = lrs[t] / bc1;
+    const float step_size = hp[0] / bc1;
     const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0) && ((uintptr_t)sh % 8 == 0) && (s0 % 4 == 0);
     long long i = s0;
     if (vec) {
@@ -227,6 +220,29 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const unsigned long lon
         const float r = adam_one(pp, g[i], mm, vv, b1, b2, eps, step_size, bc2_sqrt, gscale);
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (sh) sh[i] = (bf16_t)r;
+    }
+}
+
+// after the Adam launch (stream order): the tensors of that launch have taken one more step - unless the step was skipped for overflow.
+// With a scaler this launch also applies the GradScaler update law (one thread).
+__global__ void adam_finish_kernel(int* __restrict__ steps, const int* __restrict__ step_slot, int n_tensors, float* __restrict__ gs,
+                                   float growth, float backoff, int interval) {
+    const bool skipped = gs && gs[GS_INF] != 0.f;
+    __syncthreads();                                              // everyone has read found_inf before thread 0 clears it
+    if (!skipped)
+        for (int t = threadIdx.x; t < n_tensors; t += blockDim.x) steps[step_slot[t]] += 1;
+    if (gs && threadIdx.x == 0) {
+        if (skipped) {
+            gs[GS_SCALE] *= backoff;
+            gs[GS_TRACK] = 0.f;
+        } else {
+            gs[GS_STEP] += 1.f;
+            const float tr = gs[GS_TRACK] + 1.f;
+            if (tr >= (float)interval) { gs[GS_SCALE] *= growth; gs[GS_TRACK] = 0.f; }
+            else gs[GS_TRACK] = tr;
+        }
+        gs[GS_INV] = 1.0f / gs[GS_SCALE];
+        gs[GS_INF] = 0.f;
     }
 }
 
@@ -306,31 +322,24 @@ extern "C" int av_adam_step(float* p, const float* g, float* m, float* v, long l
     return AV_OK;
 }
 
-extern "C" int av_adam_multi(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
-                             int n_chunks, int chunk_elems, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
-    AV_CHECK(ptrs && sizes && lrs && chunk_tensor && chunk_start && n_chunks >= 0 && chunk_elems > 0 && step >= 1, "av_adam_multi: bad args");
-    if (n_chunks == 0) return AV_OK;
-    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)ptrs, sizes, lrs,
-                       chunk_tensor, chunk_start, chunk_elems, beta1, beta2, eps, bc1, bc2s, grad_scale, (const float*)nullptr);
-    AV_LAUNCH_CHECK();
-    return AV_OK;
-}
-
-extern "C" int av_adam_multi_scaled(const void* ptrs, const long long* sizes, const float* lrs, const int* chunk_tensor, const long long* chunk_start,
-                                    int n_chunks, int chunk_elems, float beta1, float beta2, float eps, float grad_scale, float* scaler_state,
-                                    float growth, float backoff, int growth_interval, void* stream) {
-    AV_CHECK(ptrs && sizes && lrs && chunk_tensor && chunk_start && n_chunks >= 0 && chunk_elems > 0 && scaler_state && growth_interval >= 1,
-             "av_adam_multi_scaled: bad args");
+extern "C" int av_adam_multi(const void* ptrs, const long long* sizes, const float* hyper, const int* chunk_tensor, const long long* chunk_start,
+                             int n_chunks, int chunk_elems, int* steps, const int* step_slot, int n_tensors, float grad_scale,
+                             float* scaler_state, float growth, float backoff, int growth_interval, void* stream) {
+    AV_CHECK(ptrs && sizes && hyper && chunk_tensor && chunk_start && steps && step_slot && n_chunks >= 0 && n_tensors >= 0 && chunk_elems > 0,
+             "av_adam_multi: bad args");
+    AV_CHECK(((uintptr_t)hyper % 16) == 0, "av_adam_multi: hyper must be 16-byte aligned ([n_tensors][4] floats)");
+    AV_CHECK(!scaler_state || growth_interval >= 1, "av_adam_multi: bad growth interval");
     hipStream_t st = (hipStream_t)stream;
     if (n_chunks > 0) {
-        hipLaunchKernelGGL(grad_check_multi_kernel, dim3(n_chunks), dim3(256), 0, st, (const unsigned long long*)ptrs, sizes, chunk_tensor, chunk_start,
-                           chunk_elems, scaler_state);
-        hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, st, (const unsigned long long*)ptrs, sizes, lrs, chunk_tensor, chunk_start,
-                           chunk_elems, beta1, beta2, eps, 1.f, 1.f, grad_scale, (const float*)scaler_state);
+        if (scaler_state)
+            hipLaunchKernelGGL(grad_check_multi_kernel, dim3(n_chunks), dim3(256), 0, st, (const unsigned long long*)ptrs, sizes, chunk_tensor,
+                               chunk_start, chunk_elems, scaler_state);
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, st, (const unsigned long long*)ptrs, sizes, (const f32x4*)hyper,
+                           chunk_tensor, chunk_start, chunk_elems, (const int*)steps, step_slot, grad_scale, (const float*)scaler_state);
     }
-    hipLaunchKernelGGL(grad_scaler_update_kernel, dim3(1), dim3(64), 0, st, scaler_state, growth, backoff, growth_interval);
+    if (n_tensors > 0 || scaler_state)
+        hipLaunchKernelGGL(adam_finish_kernel, dim3(1), dim3(256), 0, st, steps, step_slot, n_tensors, scaler_state, growth, backoff,
+                           growth_interval);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

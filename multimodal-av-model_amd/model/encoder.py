@@ -164,6 +164,19 @@ class VisualEncoder(nn.Module):
             self._wcache[key] = hit
         return hit[1]
 
+    def warm_caches(self, dtype) -> None:
+        """Build (or refresh) every cached weight re-layout on the CURRENT stream.  The trainer runs the two lip streams on two HIP streams;
+        called before they fork, so that the following stream never reads a re-layout the leading stream is still writing (first step)."""
+        conv0 = self.frontend3D[0]
+        if dtype == torch.bfloat16 and tuple(conv0.kernel_size) == (5, 7, 7):
+            self._w_front(conv0)
+        self._w(conv0, dtype)
+        for li in range(1, 5):
+            for blk in getattr(self.trunk, f"layer{li}"):
+                self._w(blk.conv1, dtype); self._w(blk.conv2, dtype)
+                if blk.downsample is not None:
+                    self._w(blk.downsample[0], dtype)
+
     def _bn(self, bn: nn.Module, stats, nblk: int, count: int, training: bool):
         C = bn.num_features
         dev = bn.weight.device

@@ -198,6 +198,8 @@ class MultimodalTrainer:
             main = torch.cuda.current_stream(dev_)
             two = self._vstream2 is not self._vstream
             evs = []
+            from ..precision import compute_dtype
+            self.visual_encoder.warm_caches(compute_dtype())       # weight re-layouts are built on main, before the lip streams fork
             self._vstream.wait_stream(main)
             with torch.cuda.stream(self._vstream):
                 if two:
@@ -352,6 +354,8 @@ class MultimodalTrainer:
                     print(f"[Batch {batch_idx}] CTC1: {out['loss1'].item():.4f}, CTC2: {out['loss2'].item():.4f}, "
                           f"Contrast1: {float(out['contrast1']):.4f}, Contrast2: {float(out['contrast2']):.4f}, "
                           f"Total: {out['total'].item():.4f}", flush=True)
+            except NotImplementedError:  # a configuration this build does not cover: every later batch would fail the same way
+                raise
             except Exception as e:       # model/trainer.py:162-164: skip the batch, keep going
                 print(f"Error at batch {batch_idx}: {e}", flush=True)
                 if self.reducer is not None and self.reducer.world > 1:

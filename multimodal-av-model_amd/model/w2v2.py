@@ -188,6 +188,30 @@ class Wav2Vec2ModelHIP(nn.Module):
             return ops.cast(w.view(G, Hd // G, k * Cg), dtype)
         return self._cache.get(("posw",), [g, v], dtype, make)
 
+    def warm_caches(self, dtype) -> None:
+        """Materialise, on the CURRENT stream, every compute-dtype copy / re-layout the forward reads (and rebuild the stale ones).  The two
+        audio passes of a step run on two streams: a cache rebuilt lazily by pass 1's host code is written on the main stream AFTER the
+        point the pass-2 stream waited for, i.e. pass 2 could read a freshly allocated, not yet written buffer (the cause of the divergence
+        of the as-executed batch-64 run in round 2, profiles/r03_nan_hunt_*).  Called before the streams fork, so that no cache is ever
+        built inside a forked region."""
+        if dtype == torch.float32:
+            self.pos_w(dtype)
+            for li in range(self.cfg["num_hidden_layers"]):
+                self.qkv_w(li, dtype); self.qkv_b(li)
+            for i in range(1, len(self.cfg["conv_kernel"])):
+                self.conv_w(i, dtype)
+            return
+        for i in range(1, len(self.cfg["conv_kernel"])):
+            self.conv_w(i, dtype)
+        self.c("feature_projection.projection.weight", dtype)
+        self.pos_w(dtype)
+        for li in range(self.cfg["num_hidden_layers"]):
+            p = f"encoder.layers.{li}."
+            self.qkv_w(li, dtype); self.qkv_b(li)
+            self.c(p + "attention.out_proj.weight", dtype)
+            self.c(p + "feed_forward.intermediate_dense.weight", dtype)
+            self.c(p + "feed_forward.output_dense.weight", dtype)
+
     # ---- which layers need a backward -----------------------------------------------------------------------
     def trainable_layers(self) -> List[bool]:
         if getattr(self, "_layer_params", None) is None:
@@ -604,6 +628,7 @@ class _EncodeFn(torch.autograd.Function):
             if getattr(model, "_pass_stream", None) is None:
                 model._pass_stream = torch.cuda.Stream(device=dev)
             side = model._pass_stream
+            model.warm_caches(compute_dtype())                       # cache (re)builds happen HERE, on main, ahead of the fork
             start = torch.cuda.Event(); start.record(main)           # everything enqueued before this forward (weights of the last Adam step ...)
         for i, (am, vl) in enumerate(zip(masks, valid)):
             if two_streams and i == 1:

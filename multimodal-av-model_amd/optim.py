@@ -44,50 +44,131 @@ class AvGradScaler:
     def state_dict(self):
         st = self.state.tolist()
         return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
-                "growth_interval": self.growth_interval, "_growth_tracker": int(st[3])}
+                "growth_interval": self.growth_interval, "_growth_tracker": int(st[3]), "_steps_taken": int(st[4])}
 
     def load_state_dict(self, sd):
         self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
         self.growth_interval = int(sd["growth_interval"])
         self.state[0] = float(sd["scale"]); self.state[1] = 1.0 / float(sd["scale"]); self.state[3] = float(sd["_growth_tracker"])
+        self.state[4] = float(sd.get("_steps_taken", 0))
+
+
+class _Plan:
+    """Static part of one multi-tensor launch (cached per set of (parameter, hyper-parameters)): sizes, {lr, beta1, beta2, eps} per tensor,
+    chunk table, step-table slots - and the pointer table of its last launch (re-uploaded only when a pointer changed)."""
+    __slots__ = ("sizes", "hyper", "ct", "cs", "slots", "nch", "n", "ptr_list", "ptr_host", "ptr_dev", "ptr_evt")
 
 
 class AvAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics, one fused launch per step whatever the set of parameters that received a gradient: step counts are
+    PER TENSOR (torch keeps ``state[p]['step']`` per parameter; LayerDrop leaves a whole layer without gradients now and then,
+    hf:774-789) and live in a device table the kernel reads and a trailing one-block launch advances.  The host-side ``state[p]['step']``
+    mirrors it exactly without loss scaling; under loss scaling the device decides which steps count (``sync_steps``)."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = 1.0
+        self._plans = {}
+        self._slot = None             # id(parameter) -> slot in the device step table
+        self._steps_dev = None
+        self._steps_seeded = False
+        self.fused_launches = 0       # diagnostics / tests: every step is one av_adam_multi call
 
     CHUNK = 65536
 
-    def _plan(self, plist):
-        """Static part of the multi-tensor launch: sizes, learning rates, chunk table (cached per parameter set)."""
-        key = tuple((p.data_ptr(), p.numel(), lr) for p, lr, _ in plist)
-        if getattr(self, "_plan_key", None) != key:
-            dev = plist[0][0].device
-            sizes = torch.tensor([p.numel() for p, _, _ in plist], dtype=torch.long, device=dev)
-            lrs = torch.tensor([lr for _, lr, _ in plist], dtype=torch.float32, device=dev)
+    def _slots(self):
+        if self._slot is None:
+            self._slot, n = {}, 0
+            for group in self.param_groups:
+                for p in group["params"]:
+                    self._slot[id(p)] = n
+                    n += 1
+        return self._slot
+
+    def _step_table(self, dev):
+        """Device int32 table of per-parameter step counts, seeded from the host state (fresh optimizer: zeros; after load_state_dict:
+        the checkpoint's counts)."""
+        slots = self._slots()
+        if self._steps_dev is None or self._steps_dev.device != torch.device(dev):
+            self._steps_dev = torch.zeros(max(1, len(slots)), dtype=torch.int32, device=dev)
+            self._steps_seeded = False
+        if not self._steps_seeded:
+            import numpy as np
+            host = np.zeros(max(1, len(slots)), dtype=np.int32)
+            for group in self.param_groups:
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st and "step" in st:
+                        host[slots[id(p)]] = int(st["step"])
+            self._steps_dev.copy_(ops.h2d_async(host, dev))
+            self._steps_seeded = True
+        return self._steps_dev
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():                              # torch >= 2 stores 'step' as a tensor in its own checkpoints
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = int(st["step"])
+        self._steps_seeded = False                                  # the device table is re-seeded from the loaded counts
+
+    def reset_state(self) -> None:
+        """Forget moments and step counts (a fresh optimizer over the same parameters)."""
+        self.state.clear()
+        self._steps_seeded = False
+        self._keep = None
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._slot = None
+        self._steps_dev = None
+        self._plans = {}
+
+    def _plan(self, plist, dev) -> _Plan:
+        slots = self._slots()
+        key = tuple((p.data_ptr(), p.numel(), hp, slots[id(p)]) for p, hp, _ in plist)
+        pl = self._plans.get(key)
+        if pl is None:
+            import numpy as np
+            if len(self._plans) >= 64:                              # LayerDrop patterns: a handful of distinct parameter sets
+                self._plans.clear()
+            pl = _Plan()
             ct, cs = [], []
             for t, (p, _, _) in enumerate(plist):
                 for s0 in range(0, p.numel(), self.CHUNK):
                     ct.append(t); cs.append(s0)
-            self._plan_key = key
-            self._plan_data = (sizes, lrs, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(cs, dtype=torch.long, device=dev), len(ct))
-        return self._plan_data
+            pl.sizes = ops.h2d_async(np.asarray([p.numel() for p, _, _ in plist], dtype=np.int64), dev)
+            pl.hyper = ops.h2d_async(np.asarray([hp for _, hp, _ in plist], dtype=np.float32).reshape(-1, 4), dev)
+            pl.ct = ops.h2d_async(np.asarray(ct, dtype=np.int32), dev)
+            pl.cs = ops.h2d_async(np.asarray(cs, dtype=np.int64), dev)
+            pl.slots = ops.h2d_async(np.asarray([slots[id(p)] for p, _, _ in plist], dtype=np.int32), dev)
+            pl.nch, pl.n = len(ct), len(plist)
+            pl.ptr_list = pl.ptr_evt = None
+            pl.ptr_host = torch.empty(5 * len(plist), dtype=torch.long).pin_memory()
+            pl.ptr_dev = torch.empty(5 * len(plist), dtype=torch.long, device=dev)
+            self._plans[key] = pl
+        return pl
 
     @torch.no_grad()
-    def sync_steps(self, scaler: "AvGradScaler") -> None:
-        """Under loss scaling the number of steps actually taken lives on the device (overflowing steps are skipped without telling
-        the host): copy it into the torch.optim.Adam-compatible ``state[p]['step']`` entries (one host sync; checkpoints)."""
-        n = scaler.steps_taken()
-        for st in self.state.values():
-            if "step" in st:
-                st["step"] = n
+    def sync_steps(self, scaler: "AvGradScaler" = None) -> None:
+        """Copy the device-side per-parameter step counts into the torch.optim.Adam-compatible ``state[p]['step']`` entries (one host
+        sync; checkpoints).  Needed under loss scaling, where overflowing steps are skipped without telling the host."""
+        if self._steps_dev is None or not self._steps_seeded:
+            return
+        host = self._steps_dev.tolist()
+        slots = self._slots()
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    st["step"] = int(host[slots[id(p)]])
 
     def step(self, closure=None, scaler: "AvGradScaler" = None):
-        """One fused multi-tensor launch for all parameters that have a gradient (same step count, per-group lr)."""
+        """One fused multi-tensor launch for all parameters that have a gradient (per-tensor step counts, per-group lr / betas / eps)."""
         loss = closure() if closure is not None else None
         plist = []
         for group in self.param_groups:
+            b1, b2 = group["betas"]
+            hp = (float(group["lr"]), float(b1), float(b2), float(group["eps"]))
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -98,62 +179,37 @@ class AvAdam(torch.optim.Optimizer):
                     state["step"] = 0
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["step"] = int(state["step"]) + 1
-                plist.append((p, float(group["lr"]), state))
+                plist.append((p, hp, state))
         if not plist:
             return loss
-        steps = {st["step"] for _, _, st in plist}
-        b1, b2 = self.param_groups[0]["betas"]
-        eps = float(self.param_groups[0]["eps"])
-        if len(steps) != 1 or any(g["betas"] != (b1, b2) or g["eps"] != eps for g in self.param_groups):
-            if scaler is not None:
-                raise NotImplementedError("AvAdam: loss scaling needs one step count / betas / eps for all parameters (the fused path)")
-            return self._step_per_tensor(plist, loss)
-        sizes, lrs, ct, cs, nch = self._plan(plist)
+        dev = plist[0][0].device
+        steps = self._step_table(dev)                               # BEFORE the host counts move: a fresh table is seeded from them
+        pl = self._plan(plist, dev)
         grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p, _, _ in plist]
         shadows = shadow.lookup_many([p for p, _, _ in plist])  # bf16 compute copies (perf path), written by the kernel
         flat = []
         for (p, _, st), g, sh in zip(plist, grads, shadows):
             flat += [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), sh.data_ptr() if sh is not None else 0]
-        if getattr(self, "_ptr_list", None) != flat:            # the caching allocator usually hands the gradients the same blocks
-            dev = plist[0][0].device
-            if getattr(self, "_ptr_host", None) is None or self._ptr_host.numel() != len(flat):
-                self._ptr_host = torch.empty(len(flat), dtype=torch.long).pin_memory()
-                self._ptr_dev = torch.empty(len(flat), dtype=torch.long, device=dev)
-                self._ptr_evt = None
-            if self._ptr_evt is not None:
-                self._ptr_evt.synchronize()                     # the previous upload has left the pinned buffer
-            self._ptr_host.copy_(torch.tensor(flat, dtype=torch.long))
-            self._ptr_dev.copy_(self._ptr_host, non_blocking=True)
-            self._ptr_evt = torch.cuda.Event(); self._ptr_evt.record()
-            self._ptr_list = flat
+        if pl.ptr_list != flat:                                     # the caching allocator usually hands the gradients the same blocks
+            if pl.ptr_evt is not None:
+                pl.ptr_evt.synchronize()                            # the previous upload has left the pinned buffer
+            pl.ptr_host.copy_(torch.tensor(flat, dtype=torch.long))
+            pl.ptr_dev.copy_(pl.ptr_host, non_blocking=True)
+            pl.ptr_evt = torch.cuda.Event(); pl.ptr_evt.record()
+            pl.ptr_list = flat
         if scaler is not None:
-            if getattr(self, "_scaler_seeded", None) is not scaler:       # resume: the device-side step count starts from the optimizer's
-                scaler.state[4] = float(steps.pop() - 1)
-                self._scaler_seeded = scaler
-            L.check(L.lib().av_adam_multi_scaled(ops.ptr(self._ptr_dev), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK,
-                                                 float(b1), float(b2), eps, float(self.grad_scale), ops.ptr(scaler.state), scaler.growth_factor,
-                                                 scaler.backoff_factor, scaler.growth_interval, ops.stream()), "av_adam_multi_scaled")
+            L.check(L.lib().av_adam_multi(ops.ptr(pl.ptr_dev), ops.ptr(pl.sizes), ops.ptr(pl.hyper), ops.ptr(pl.ct), ops.ptr(pl.cs), pl.nch,
+                                          self.CHUNK, ops.ptr(steps), ops.ptr(pl.slots), pl.n, float(self.grad_scale), ops.ptr(scaler.state),
+                                          scaler.growth_factor, scaler.backoff_factor, scaler.growth_interval, ops.stream()), "av_adam_multi")
         else:
-            L.check(L.lib().av_adam_multi(ops.ptr(self._ptr_dev), ops.ptr(sizes), ops.ptr(lrs), ops.ptr(ct), ops.ptr(cs), nch, self.CHUNK, float(b1),
-                                          float(b2), eps, steps.pop(), float(self.grad_scale), ops.stream()), "av_adam_multi")
+            L.check(L.lib().av_adam_multi(ops.ptr(pl.ptr_dev), ops.ptr(pl.sizes), ops.ptr(pl.hyper), ops.ptr(pl.ct), ops.ptr(pl.cs), pl.nch,
+                                          self.CHUNK, ops.ptr(steps), ops.ptr(pl.slots), pl.n, float(self.grad_scale), None, 1.0, 1.0, 1,
+                                          ops.stream()), "av_adam_multi")
+            for _, _, st in plist:                                  # exact host mirror (with a scaler the device decides: sync_steps)
+                st["step"] = int(st["step"]) + 1
+        self.fused_launches += 1
         self._keep = grads                                      # alive until the next step (stream-ordered use)
         params = [p for p, _, _ in plist]
         torch.autograd.graph.increment_version(params)          # other compute-dtype caches (re-layouts) rebuild
         shadow.mark_fresh([p for p, sh in zip(params, shadows) if sh is not None])      # ... the shadows were just written
-        return loss
-
-    def _step_per_tensor(self, plist, loss):
-        st_ = ops.stream()
-        fn = L.lib().av_adam_step
-        for group in self.param_groups:
-            b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                state = self.state[p]
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                L.check(fn(ops.ptr(p), ops.ptr(g), ops.ptr(state["exp_avg"]), ops.ptr(state["exp_avg_sq"]), p.numel(), float(group["lr"]),
-                           float(b1), float(b2), float(group["eps"]), state["step"], float(self.grad_scale), st_), "av_adam_step")
-                torch.autograd.graph.increment_version(p)
         return loss
