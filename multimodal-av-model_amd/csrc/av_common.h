@@ -103,11 +103,13 @@ __device__ __forceinline__ void gelu_both_fast(float x, float& gl, float& gp) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// ---- counter-based RNG (Philox2x32-10, Salmon et al. SC'11) for dropout: the mask of element `idx` of stream `stream` under `seed`
-// is a pure function of (seed, stream, idx), so the backward pass regenerates exactly the forward's mask without storing it.
-// One Philox block (64-bit counter = idx / 4, 32-bit key mixed from seed and stream) yields 64 bits = FOUR 16-bit uniforms, one per
-// element of an aligned group of 4: one multiply pair per round and element group (the 4x32 form spent two), and the drop
-// probability is resolved to 2^-16.
+// ---- counter-based RNG for dropout: the mask of element `idx` of stream `stream` under `seed` is a pure function of (seed, stream, idx),
+// so the backward pass regenerates exactly the forward's mask without storing it.  An aligned group of four elements draws 64 bits = FOUR
+// 16-bit uniforms (the drop probability is resolved to 2^-16) from a bijective 32-bit integer mixer - two multiply-xorshift rounds with the
+// "lowbias32" constants of C. Wellons' hash prospector (avalanche bias 0.17) - evaluated at two inputs derived from the group index and a
+// 32-bit key mixed from seed and stream.  Rounds 1-2 of this build used Philox2x32-10 here: its ten 32 x 32 -> 64-bit multiplies per group
+// (v_mul_lo_u32 + v_mul_hi_u32, quarter-rate instructions) were a quarter of the FFN-up GEMM's epilogue time while its matrix pipes idled;
+// the mixer needs four.  Dropout needs decorrelated, reproducible masks, not a cryptographic stream.
 __device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned stream) {
     unsigned h = (unsigned)seed * 0x9E3779B1u;
     h ^= (unsigned)(seed >> 32) * 0x85EBCA77u;
@@ -115,21 +117,16 @@ __device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned s
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return h;
 }
-__device__ __forceinline__ void philox2x32_10(unsigned c0, unsigned c1, unsigned k, unsigned& o0, unsigned& o1) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const unsigned long long pr = (unsigned long long)0xD256D193u * c0;
-        const unsigned n0 = (unsigned)(pr >> 32) ^ k ^ c1;
-        c1 = (unsigned)pr; c0 = n0;
-        k += 0x9E3779B9u;
-    }
-    o0 = c0; o1 = c1;
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
 }
 // the four 16-bit uniforms (as floats in [0,1)) of the aligned group that starts at element idx4 (a multiple of 4)
 __device__ __forceinline__ void drop_uniform4(unsigned long long seed, unsigned stream, unsigned long long idx4, float (&u)[4]) {
     const unsigned long long blk = idx4 >> 2;
-    unsigned o0, o1;
-    philox2x32_10((unsigned)blk, (unsigned)(blk >> 32), drop_key(seed, stream), o0, o1);
+    const unsigned c1 = (unsigned)(blk >> 32);                                     // non-zero only beyond 2^34 elements
+    const unsigned x = (unsigned)blk ^ drop_key(seed, stream) ^ c1 ^ __builtin_rotateleft32(c1, 11) ^ __builtin_rotateleft32(c1, 23);
+    const unsigned o0 = mix32(x), o1 = mix32(x + 0x9E3779B9u);
     u[0] = (float)(o0 & 0xFFFFu) * (1.0f / 65536.0f); u[1] = (float)(o0 >> 16) * (1.0f / 65536.0f);
     u[2] = (float)(o1 & 0xFFFFu) * (1.0f / 65536.0f); u[3] = (float)(o1 >> 16) * (1.0f / 65536.0f);
 }
@@ -148,7 +145,7 @@ __device__ __forceinline__ float drop_mult(unsigned long long seed, unsigned str
 __device__ __noinline__ float drop_mult_call(unsigned long long seed, unsigned stream, unsigned long long idx, float p, float inv_keep) {
     return drop_mult(seed, stream, idx, p, inv_keep);
 }
-// 4 consecutive elements starting at a multiple of 4 (one Philox call)
+// 4 consecutive elements starting at a multiple of 4 (one generator call)
 __device__ __forceinline__ void drop_mult4(unsigned long long seed, unsigned stream, unsigned long long idx4, float p, float inv_keep, float (&m)[4]) {
     float u[4];
     drop_uniform4(seed, stream, idx4, u);

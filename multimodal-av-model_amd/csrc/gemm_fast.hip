@@ -25,6 +25,16 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_line[256];   // source of padded / out-of-range rows
 
+// Diagnostic build only (-DAV_GEMM_STAMPS, tools/gemm_stamps.py): wall-clock stamps (s_memrealtime, 100 MHz) of every workgroup of the
+// 8-phase kernel at entry / first MFMA phase / end of the main loop / exit, into a buffer nothing else reads.  No stamp exists in the
+// product build.
+#ifdef AV_GEMM_STAMPS
+__device__ unsigned long long g_gemm_stamps[8192 * 4];
+#define AV_STAMP(SLOT) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 4 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AV_STAMP(SLOT) do { } while (0)
+#endif
+
 // NWI wave-instructions per wave, each filling 8 tile rows x 128 B (lane -> row sub = lane>>3, physical chunk lane&7;
 // the global chunk is pch ^ sub: XOR swizzle applied on the SOURCE side, LDS image stays lane-linear)
 template <int NWI>
@@ -898,6 +908,7 @@ __device__ __forceinline__ void stage_conv2(const av_gemm_args& p, const ConvRow
 template <bool CONV>
 __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl, const int nfull, const int bm_eff) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    AV_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
     const int wr = __builtin_amdgcn_readfirstlane(w >> 2), wc = w & 3;
     const int r = lane & 15, g = lane >> 4;
@@ -972,6 +983,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     __builtin_amdgcn_s_barrier();                            // K-tile 0 landed for everyone
     asm volatile("" ::: "memory");
     if (wr == 1) __builtin_amdgcn_s_barrier();       // wavefronts 4-7 run one barrier behind
+    AV_STAMP(1);
 
     const int sw = r & 7;
     const int ch0 = (g ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
@@ -1026,6 +1038,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #undef V4_READ_B
 #undef V4_MMA
     if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the entry barrier of wavefronts 4-7
+    AV_STAMP(2);
 
     float* cs = (float*)smem;
     const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
@@ -1094,6 +1107,10 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
             o[p.N + n0 + tid] = red[256 + tid] + red[768 + tid];
         }
     }
+#ifdef AV_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // diagnostic: the exit stamp includes the completion of this workgroup's stores
+#endif
+    AV_STAMP(3);
 }
 
 template <int BNT, bool CONV, bool AKM = false, bool BKM = false>
@@ -1227,6 +1244,12 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     if (conv) return narrow ? launch_fast<64, true>(p, st, fl) : launch_fast<128, true>(p, st, fl);
     return narrow ? launch_fast<64, false>(p, st, fl) : launch_fast<128, false>(p, st, fl);
 }
+
+#ifdef AV_GEMM_STAMPS
+extern "C" int av_gemm_stamps_read(unsigned long long* host_out, int n_blocks) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int av_transpose(const void* in, int idt, void* out, int odt, int R, int C, long long ldi, int Rpad, void* stream) {
     AV_CHECK(in && out && R > 0 && C > 0 && ldi >= C && Rpad >= R, "av_transpose: bad args R=%d C=%d ldi=%lld Rpad=%d", R, C, ldi, Rpad);

@@ -239,3 +239,33 @@ def test_specaugment_time_and_feature_masks_vs_hf_model():
     with torch.no_grad():
         last0, _ = ae(wav.cuda(), attention_mask=am.bool().cuda())
     assert float((last0 - last).abs().max()) > 1e-2
+
+
+def test_dropout_uniform_generator_statistics():
+    """The counter-based generator behind every dropout mask (av_common.h: drop_uniform4): uniform 16-bit marginals, no correlation
+    between neighbouring elements, between the two words of a group, or between streams / seeds at the same positions."""
+    L = pkg("_lib"); ops = pkg("ops")
+    n = 1 << 22
+
+    def draw(seed, stream):
+        u = torch.empty(n, device="cuda", dtype=torch.float32)
+        L.check(L.lib().av_dropout_uniform(ops.ptr(u), n, seed, stream, ops.stream()))
+        return u.double()
+
+    u = draw(1234, 5)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 1e-3 and abs(float(u.var()) - 1.0 / 12.0) < 1e-3
+    hist = torch.histc(u.float(), bins=256, min=0.0, max=1.0).double()
+    chi2 = float(((hist - n / 256) ** 2 / (n / 256)).sum())
+    assert 150 < chi2 < 400, chi2                                 # 255 degrees of freedom: mean 255, sd 22.6
+
+    def corr(a, b):
+        a = a - a.mean(); b = b - b.mean()
+        return float((a * b).mean() / (a.std() * b.std()))
+    for lag in (1, 2, 3, 4, 5, 8, 199, 1024):                      # inside a group of four, across groups, across rows
+        assert abs(corr(u[:-lag], u[lag:])) < 4e-3, lag
+    for other in (draw(1234, 6), draw(1235, 5), draw(1234, 5 + 8), draw(99, 5)):
+        assert abs(corr(u, other)) < 4e-3
+        assert abs(float(((u >= 0.1) & (other >= 0.1)).double().mean()) - 0.81) < 2e-3      # joint keep rate of two p = 0.1 masks
+    # the low 16-bit lattice: every uniform is k / 65536
+    assert float((u * 65536 - torch.round(u * 65536)).abs().max()) == 0.0
