@@ -252,6 +252,10 @@ def main():
         barrier()
         torch.cuda.synchronize()
         m.layers_executed = m.layers_executed_bwd = m.layers_executed_bwd_tr = 0
+        if reducer is not None:
+            reducer.exposed_ms()                                  # drop the warm-up's event pairs
+            reducer.timing = True
+            reducer.flat_reduces = reducer.cat_reduces = 0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = t.train_step(batch)
@@ -266,7 +270,17 @@ def main():
             dt = float(tt)
         lay = (m.layers_executed / args.steps, (m.layers_executed_bwd - m.layers_executed_bwd_tr) / args.steps, m.layers_executed_bwd_tr / args.steps)
         loss_v = float(out["total"].detach())
-        return dict(dt=dt, passes=passes, loss=loss_v, layers=lay, valid=finite_state(loss_v), variant=v,
+        dpi = None
+        if reducer is not None:
+            reducer.timing = False
+            ex = reducer.exposed_ms()
+            dpi = {"ranks": world, "backend": "rccl (torch.distributed nccl)" if args.backend == "nccl" else args.backend,
+                   "gradient_bytes_per_step": int(sum(reducer.last_bucket_bytes)), "buckets_last_step_mb": [round(b / 1e6, 1) for b in reducer.last_bucket_bytes],
+                   "buckets_reduced_in_place": reducer.flat_reduces, "buckets_packed_by_copy": reducer.cat_reduces,
+                   "exposed_allreduce_ms_per_step": round(sum(ex) / max(1, len(ex)), 3),
+                   "note": "buckets = decoder + fusion (issued when the wav2vec2 backward starts) and one per trainable wav2vec2 layer, all-reduced on a side "
+                           "stream under the backward; exposed = time the main stream waited at the join before Adam (events on the main stream)"}
+        return dict(dt=dt, passes=passes, loss=loss_v, layers=lay, valid=finite_state(loss_v), variant=v, dp=dpi,
                     scale=(t.scaler.get_scale(), t.scaler.steps_taken()) if args.loss_scaling else None)
 
     def diverged(leg):
@@ -336,6 +350,8 @@ def main():
                                                         "backward_dx_dw": round(leg["layers"][2], 2)},
                    "algorithmic_gflop_per_utt": round(fl / 1e9, 1), "step_tflops": round(fl * utt / 1e12, 1),
                    "step_frac_of_mfma_peak": round(fl * utt / 1e12 / peak, 4)}
+            if leg.get("dp") is not None:
+                out["data_parallel"] = leg["dp"]
             if leg["scale"] is not None:
                 out["loss_scaling"] = {"law": "torch.amp.GradScaler (init 65536, x2 / 2000 clean steps, x0.5 on overflow, overflowing steps skipped)",
                                        "final_scale": leg["scale"][0], "optimizer_steps_taken": leg["scale"][1]}
@@ -375,7 +391,7 @@ def main():
                           "audio_passes": head["audio_passes"], "wav2vec2_regularizers": head["wav2vec2_regularizers"],
                           "lambda_contrastive": args.lambda_, "final_loss": head["final_loss"],
                           "encoder_layers_executed_per_step": head["encoder_layers_executed_per_step"],
-                          "loss_scaling": head.get("loss_scaling"),
+                          "loss_scaling": head.get("loss_scaling"), "data_parallel": head.get("data_parallel"),
                           "algorithmic_gflop_per_utt": head["algorithmic_gflop_per_utt"],
                           "step_tflops": head["step_tflops"], "step_frac_of_mfma_peak": head["step_frac_of_mfma_peak"]},
                "valid": True, "roofline": roof}

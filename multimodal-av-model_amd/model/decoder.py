@@ -14,13 +14,14 @@ from ..utils.shadow import ParamCache
 
 class _HeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(fctx, x, w, b, wt):
+    def forward(fctx, x, w, b, wt, arena):
         dtype = compute_dtype()
         xt = ops.cast(x.contiguous().float(), dtype)
         logits = ops.linear(xt, wt, b.data, out_dtype=torch.float32)
         lp = ops.log_softmax_fwd(logits)
         fctx.save_for_backward(xt, wt, lp)
         fctx.dtype = dtype
+        fctx.arena = arena
         return lp
 
     @staticmethod
@@ -30,9 +31,11 @@ class _HeadFn(torch.autograd.Function):
         dlogits = ops.log_softmax_bwd(lp, dlp.contiguous().float(), fctx.dtype)
         d2 = dlogits.view(-1, V)
         dx = ops.matmul_nn(d2, wt, out_dtype=torch.float32).view(xt.shape) if fctx.needs_input_grad[0] else None
-        dw = ops.matmul_tn(d2, xt.view(-1, D)) if fctx.needs_input_grad[1] else None
-        db = ops.colsum(d2) if fctx.needs_input_grad[2] else None
-        return dx, dw, db, None
+        ar, dev = fctx.arena, d2.device
+        A = (lambda n, shp: ar.out("decoder." + n, shp, dev)) if ar is not None else (lambda n, shp: None)
+        dw = ops.matmul_tn(d2, xt.view(-1, D), out=A("weight", (V, D))) if fctx.needs_input_grad[1] else None
+        db = ops.colsum(d2, out=A("bias", (V,))) if fctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
 
 
 class CTCDecoder(nn.Module):
@@ -41,6 +44,7 @@ class CTCDecoder(nn.Module):
         self.net = nn.Sequential(nn.Linear(input_dim, vocab_size))     # parameter container: keys net.0.{weight,bias}
         self.ctc_loss = nn.CTCLoss(blank=blank_id, zero_infinity=True)
         self._cache = ParamCache()
+        self.grad_arena = None          # parallel.dp.GradArena shared with the fusion module (the trainer's head gradient bucket)
 
     def forward(self, x, target=None, input_lengths=None, target_lengths=None):
         """x [B,T,D] -> log-probs [B,T,V], or the CTC loss when ``target`` is given (model/decoder.py:14-35)."""
@@ -49,7 +53,7 @@ class CTCDecoder(nn.Module):
         lin = self.net[0]
         dtype = compute_dtype()
         wt = lin.weight.data if dtype == torch.float32 else self._cache.get("w", [lin.weight], dtype, lambda: ops.cast(lin.weight.data.contiguous(), dtype), flat=True)
-        log_probs = _HeadFn.apply(x, lin.weight, lin.bias, wt)
+        log_probs = _HeadFn.apply(x, lin.weight, lin.bias, wt, self.grad_arena)
         if target is not None:
             return self.ctc_loss(log_probs.transpose(0, 1), target, input_lengths, target_lengths)
         return log_probs

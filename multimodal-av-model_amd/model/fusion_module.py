@@ -69,8 +69,10 @@ def lstm_forward(mod: "CrossAttentionFusion", x_tm: Tensor, save: bool):
 
 
 def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: Dict[str, Tensor]) -> Tensor:
-    """dout_bt [B,T,2H] fp32 -> d(x_tm) [T,B,E] compute dtype; fills ``grads`` with temporal_model.* gradients."""
+    """dout_bt [B,T,2H] fp32 -> d(x_tm) [T,B,E] compute dtype; fills ``grads`` with temporal_model.* gradients (written into the module's
+    flat gradient bucket when it has one: ``mod._grad_out``)."""
     lstm = mod.temporal_model
+    A = mod._grad_out
     H = lstm.hidden_size
     dout, do_bs, do_ts = dout_bt, dout_bt.shape[1] * 2 * H, 2 * H
     dx = None
@@ -97,14 +99,18 @@ def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: D
         M = T * B
         dg2 = dgates.view(M, 8 * H)
         in_f = inp.shape[-1]
-        dwih = ops.matmul_tn(dg2, inp.view(M, in_f))                                     # [8H, in]
-        db = ops.colsum(dg2)                                                             # [8H]
+        dwih = ops.matmul_tn(dg2, inp.view(M, in_f), out=A(f"lstm.dwih{layer}", (8 * H, in_f), dev))     # [8H, in]
+        db = ops.colsum(dg2, out=A(f"lstm.db{layer}", (8 * H,), dev))                    # [8H]
         n = c["names"]
         grads["temporal_model." + n[0]] = dwih[:4 * H]
         grads["temporal_model." + n[1]] = dwih[4 * H:]
-        grads["temporal_model." + n[4]] = db[:4 * H]; grads["temporal_model." + n[6]] = db[:4 * H]
-        grads["temporal_model." + n[5]] = db[4 * H:]; grads["temporal_model." + n[7]] = db[4 * H:]
-        dwhh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
+        grads["temporal_model." + n[4]] = db[:4 * H]; grads["temporal_model." + n[6]] = db[:4 * H]       # (separate view objects: each
+        grads["temporal_model." + n[5]] = db[4 * H:]; grads["temporal_model." + n[7]] = db[4 * H:]       # is handed to autograd once)
+        dwhh = A(f"lstm.dwhh{layer}", (2, 4 * H, H), dev)
+        if dwhh is None:
+            dwhh = torch.zeros((2, 4 * H, H), dtype=torch.float32, device=dev)
+        elif T <= 1:
+            dwhh.zero_()
         if T > 1:
             # forward chain: dgates[t] pairs with h[t-1]; reverse chain: dgates[t] pairs with h[t+1].  Time-major buffers
             # make the one-step shift a row offset of B; the column slices are transposed to the K-contiguous fast form.
@@ -184,10 +190,14 @@ class _FusionFn(torch.autograd.Function):
         dfused = torch.empty((B, Tv, E), dtype=dtype, device=dout.device)
         L.check(L.lib().av_permute_bt(ops.ptr(dx_tm), ops.dt(dx_tm), ops.ptr(dfused), ops.dt(dfused), Tv, B, E, ops.stream()), "av_permute_bt")
         df2 = dfused.view(M, E)
-        g["fusion_proj.weight"] = ops.matmul_tn(df2, s["a2v"].view(M, E)); g["fusion_proj.bias"] = ops.colsum(df2)
+        dev = dout.device
+        A = mod._grad_out
+        g["fusion_proj.weight"] = ops.matmul_tn(df2, s["a2v"].view(M, E), out=A("fusion_proj.weight", (E, E), dev))
+        g["fusion_proj.bias"] = ops.colsum(df2, out=A("fusion_proj.bias", (E,), dev))
         da2v = ops.matmul_nn(df2, c(mod.fusion_proj.weight))
         mha = mod.cross_attn_audio
-        g["cross_attn_audio.out_proj.weight"] = ops.matmul_tn(da2v, s["o"].view(M, E)); g["cross_attn_audio.out_proj.bias"] = ops.colsum(da2v)
+        g["cross_attn_audio.out_proj.weight"] = ops.matmul_tn(da2v, s["o"].view(M, E), out=A("xa.out_proj.weight", (E, E), dev))
+        g["cross_attn_audio.out_proj.bias"] = ops.colsum(da2v, out=A("xa.out_proj.bias", (E,), dev))
         do = ops.matmul_nn(da2v, c(mha.out_proj.weight)).view(B, Tv, nh, hd)
         q, kv = s["q"], s["kv"]
         if FUSED_XATTN and dtype == torch.bfloat16 and E == 512 and nh == 4 and Tv <= 112:
@@ -197,15 +207,23 @@ class _FusionFn(torch.autograd.Function):
             ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], do, dq, dkv[:, :, 0], dkv[:, :, 1], None, hd ** -0.5, o=s["o"], lse=s["lse"])
         Win = c(mha.in_proj_weight)
         dq2, dkv2 = dq.view(M, E), dkv.view(M, 2 * E)
-        dWin = torch.empty((3 * E, E), dtype=torch.float32, device=dout.device)
+        dWin = A("xa.in_proj_weight", (3 * E, E), dev)
+        if dWin is None:
+            dWin = torch.empty((3 * E, E), dtype=torch.float32, device=dev)
         ops.matmul_tn(dq2, s["a"].view(M, E), out=dWin[:E])
         ops.matmul_tn(dkv2, s["v"].view(M, E), out=dWin[E:])
         g["cross_attn_audio.in_proj_weight"] = dWin
-        g["cross_attn_audio.in_proj_bias"] = torch.cat([ops.colsum(dq2), ops.colsum(dkv2)])
+        dbin = A("xa.in_proj_bias", (3 * E,), dev)
+        if dbin is None:
+            dbin = torch.empty(3 * E, dtype=torch.float32, device=dev)
+        ops.colsum(dq2, out=dbin[:E]); ops.colsum(dkv2, out=dbin[E:])
+        g["cross_attn_audio.in_proj_bias"] = dbin
         da = ops.matmul_nn(dq2, Win[:E])
         dv = ops.matmul_nn(dkv2, Win[E:])
-        g["audio_proj.weight"] = ops.matmul_tn(da, s["a_in_t"].view(M, Da)); g["audio_proj.bias"] = ops.colsum(da)
-        g["visual_proj.weight"] = ops.matmul_tn(dv, s["vis_t"].view(M, Dv)); g["visual_proj.bias"] = ops.colsum(dv)
+        g["audio_proj.weight"] = ops.matmul_tn(da, s["a_in_t"].view(M, Da), out=A("audio_proj.weight", (E, Da), dev))
+        g["audio_proj.bias"] = ops.colsum(da, out=A("audio_proj.bias", (E,), dev))
+        g["visual_proj.weight"] = ops.matmul_tn(dv, s["vis_t"].view(M, Dv), out=A("visual_proj.weight", (E, Dv), dev))
+        g["visual_proj.bias"] = ops.colsum(dv, out=A("visual_proj.bias", (E,), dev))
         d_audio = d_visual = None
         if fctx.need_audio:
             da_in = ops.matmul_nn(da, c(mod.audio_proj.weight), out_dtype=torch.float32)       # [M, Da]
@@ -230,6 +248,7 @@ class CrossAttentionFusion(nn.Module):
         self.temporal_model = nn.LSTM(input_size=fused_dim, hidden_size=fused_dim, num_layers=2, batch_first=True, bidirectional=True)
         self.fused_dim, self.num_heads = fused_dim, num_heads
         self._cache = ParamCache()
+        self.grad_arena = None         # parallel.dp.GradArena shared with the CTC head (the trainer's decoder + fusion gradient bucket)
         self._lstm_flags = []          # arrival/timeout words of the persistent LSTM launches (checked lazily)
         self._flag_host, self._flag_evt, self._flag_n = None, None, 0
         if fused_dim % 32 or (fused_dim // num_heads) not in (16, 32, 64, 128):
@@ -260,6 +279,10 @@ class CrossAttentionFusion(nn.Module):
         if bad:
             raise RuntimeError("persistent LSTM kernel: inter-workgroup wait timed out (the step that launched it is invalid); "
                                "AVAMD_LSTM_PERSISTENT=0 selects the per-step kernels (e.g. on a GPU shared with other processes)")
+
+    def _grad_out(self, name: str, shape, device):
+        """View of the flat gradient bucket for this gradient, or None (no bucket / layout not known yet / already written this step)."""
+        return self.grad_arena.out("fusion." + name, shape, device) if self.grad_arena is not None else None
 
     def cparam(self, p: Tensor, dtype) -> Tensor:
         if dtype == torch.float32:

@@ -24,7 +24,7 @@ from .. import _lib as L
 from ..beam_search import fast_decode, greedy_batch
 from ..contrastive import contrastive_loss_with_mask
 from ..optim import AvAdam, AvGradScaler
-from ..parallel.dp import GradBucketReducer
+from ..parallel.dp import GradArena, GradBucketReducer
 
 
 def word_error_rate(refs, hyps) -> float:
@@ -102,6 +102,10 @@ class MultimodalTrainer:
         self.scaler = AvGradScaler(device=device, enabled=loss_scaling)
         self.projection_layer = None
         self.fixed_projection = None        # (weight, bias) to inject instead of a fresh random layer (parity tests)
+        # decoder + fusion gradients are produced straight into ONE flat buffer (no packing copy before their all-reduce, no per-step
+        # allocations, a pointer table of the fused Adam that never changes); the wav2vec2 layers keep one such buffer each
+        self._head_arena = GradArena()
+        self.fusion_module.grad_arena = self.decoder1.grad_arena = self._head_arena
         self.reducer = reducer
         if reducer is not None:
             self.optimizer.grad_scale = 1.0 / reducer.world
@@ -113,6 +117,7 @@ class MultimodalTrainer:
                 m.layerdrop_generator = torch.Generator().manual_seed(0x5EED1A7E)
                 m.dropout_generator = torch.Generator().manual_seed(0xD120 + 7919 * dist.get_rank(reducer.group))
             self.audio_encoder.model.grad_ready = reducer.reduce_async
+            self.audio_encoder.model.grad_flat_ready = reducer.reduce_flat
             self.audio_encoder.model.grad_wait = reducer.wait
             self._head_params = [p for m in (self.decoder1, self.fusion_module) for n, p in m.named_parameters()
                                  if not n.startswith("cross_attn_visual.")]
@@ -311,10 +316,15 @@ class MultimodalTrainer:
     def train_step(self, batch) -> Dict[str, torch.Tensor]:
         """zero_grad -> forward -> backward (-> bucketed all-reduce) -> Adam; no host sync."""
         self.optimizer.zero_grad(set_to_none=True)
+        self._head_arena.begin_step()
+        begin = getattr(self.audio_encoder.model, "begin_grad_step", None)
+        if begin is not None:
+            begin()
         if self.reducer is not None:
             self._head_done = False
         out = self.forward_losses(batch)
         self.scaler.scale(out["total"]).backward()                 # model/trainer.py:121
+        self._head_arena.finalize()
         if self.reducer is not None:
             # wav2vec2 layer buckets were reduced inside its backward (overlapped), the decoder + fusion bucket at its start; if that
             # backward did not run (nothing trainable below the fusion) the bucket goes now
@@ -338,8 +348,12 @@ class MultimodalTrainer:
         if self._head_done:
             return
         hp = [p for p in self._head_params if p.grad is not None]
-        for p, v in zip(hp, self.reducer.reduce_async([p.grad for p in hp])):
-            p.grad = v
+        ar = self._head_arena
+        if hp and ar.flat is not None and all(ar.owns(p.grad) for p in hp):
+            self.reducer.reduce_flat(ar)                           # the gradients ARE the bucket: all-reduced in place, nothing is packed
+        else:                                                      # first step (layout still being discovered) / two fusion calls per step
+            for p, v in zip(hp, self.reducer.reduce_async([p.grad for p in hp])):
+                p.grad = v
         self._head_done = True
 
     def train_epoch(self, dataloader):

@@ -131,7 +131,9 @@ class Wav2Vec2ModelHIP(nn.Module):
         self._names = [n for n, _ in self.named_parameters()]
         # data-parallel hooks (parallel/dp.py): per-layer gradient bucket -> async all-reduce, joined at the end of backward
         self.grad_ready = None
+        self.grad_flat_ready = None     # the same for a layer whose gradients already live in one flat buffer (GradArena): no packing copy
         self.grad_wait = None
+        self._arenas = {}               # layer -> GradArena: persistent flat gradient buffer the backward kernels write into
         self.grad_pre = None            # called when this model's backward starts (the trainer reduces the head gradients there)
         # host RNG sources of the train-mode regularisers.  None = torch's global generator (what HF uses).  Under data parallelism the
         # trainer installs a LayerDrop generator that is IDENTICAL on every rank (a dropped trainable layer issues no gradient bucket, so
@@ -469,16 +471,26 @@ class Wav2Vec2ModelHIP(nn.Module):
                 if two_streams:
                     main.wait_stream(side)
                 keys = [k for k in grads if k.startswith(p)]
-                if keys:
+                ar = self._arenas.get(li)
+                if keys and ar is not None and self.grad_flat_ready is not None and all(ar.owns(grads[k]) for k in keys):
+                    self.grad_flat_ready(ar)                        # the layer's gradients ARE the bucket: reduced in place
+                elif keys:
                     for k, v in zip(keys, self.grad_ready([grads[k] for k in keys])):
                         grads[k] = v
         if two_streams:
             main.wait_stream(side)
             for t in _tensors_of(states[1]):
                 t.record_stream(main)
+        for ar in self._arenas.values():
+            ar.finalize()                                           # first backward: the layout is known now, the buffers exist from the next step on
         if self.grad_wait is not None:
             self.grad_wait()
         return grads
+
+    def begin_grad_step(self) -> None:
+        """Called by the trainer when a step's gradients are cleared: the flat gradient buckets may be written again."""
+        for ar in self._arenas.values():
+            ar.begin_step()
 
     def _layer_backward(self, ctx: dict, st: dict, li: int, grads: Dict[str, Tensor]) -> None:
         """One encoder layer of one pass: updates st['dh'] (gradient of the residual stream below the layer) and adds the layer's weight
@@ -504,17 +516,23 @@ class Wav2Vec2ModelHIP(nn.Module):
         M = B * T
         seed, hd_p, at_p, ac_p = ctx["seed"], ctx["hd_p"], ctx["at_p"], ctx["ac_p"]
 
-        def wgrad(key, dy, x):                                       # dW (+)= dy^T x
+        ar = self._arenas.get(li)
+        if ar is None and tr:
+            from ..parallel.dp import GradArena
+            ar = self._arenas[li] = GradArena()
+        dev_ = ctx["hL"].device
+
+        def wgrad(key, dy, x):                                       # dW (+)= dy^T x; the first writer of a step writes into the layer's flat bucket
             if key in grads:
                 ops.matmul_tn(dy, x, out=grads[key], accumulate=True)
             else:
-                grads[key] = ops.matmul_tn(dy, x)
+                grads[key] = ops.matmul_tn(dy, x, out=ar.out(key, (dy.shape[1], x.shape[1]), dev_))
 
         def bgrad(key, dy):                                          # db (+)= column sums
             if key in grads:
                 ops.colsum(dy, out=grads[key], accumulate=True)
             else:
-                grads[key] = ops.colsum(dy)
+                grads[key] = ops.colsum(dy, out=ar.out(key, (dy.shape[-1],), dev_))
 
         dh3 = dh
         dh3_t = dh_lp if (fuse_lp and dh_lp is not None) else ops.cast_dropout(dh3, dtype, (hd_p, seed, li * 8 + 2))   # FFN-output dropout mask
@@ -535,7 +553,8 @@ class Wav2Vec2ModelHIP(nn.Module):
         ln2 = p + "final_layer_norm."
         r = ops.layernorm_bwd(s["h2"], dx2.view(B, T, Hd), self.P(ln2 + "weight").data, s["mu2"], s["rs2"], dres=dh3,
                               want_param_grads=tr, lp_copy=fuse_lp, lp_drop=(hd_p, seed, li * 8 + 0),   # consumer: this layer's attention-output dropout
-                              gb_acc=grads.get(ln2 + "_gb") if tr else None, packed_gb=True)
+                              gb_acc=grads.get(ln2 + "_gb") if tr else None, packed_gb=True,
+                              gb_out=ar.out(ln2 + "_gb", (2 * Hd,), dev_) if (tr and (ln2 + "_gb") not in grads) else None)
         dh2_lp = None
         if fuse_lp:
             r, dh2_lp = r[:-1], r[-1]
@@ -567,7 +586,8 @@ class Wav2Vec2ModelHIP(nn.Module):
         ln1 = p + "layer_norm."
         r = ops.layernorm_bwd(s["h"], dx1.view(B, T, Hd), self.P(ln1 + "weight").data, s["mu1"], s["rs1"], dres=dh2,
                               want_param_grads=tr, lp_copy=lp_ok, lp_drop=(hd_p, seed, lower * 8 + 2),
-                              gb_acc=grads.get(ln1 + "_gb") if tr else None, packed_gb=True)
+                              gb_acc=grads.get(ln1 + "_gb") if tr else None, packed_gb=True,
+                              gb_out=ar.out(ln1 + "_gb", (2 * Hd,), dev_) if (tr and (ln1 + "_gb") not in grads) else None)
         dh_lp = None
         if lp_ok:
             r, dh_lp = r[:-1], r[-1]

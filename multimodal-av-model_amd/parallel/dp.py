@@ -15,32 +15,83 @@ import torch
 import torch.distributed as dist
 
 
+class GradArena:
+    """One gradient bucket as ONE persistent flat fp32 buffer: the backward kernels write their weight / bias gradients straight into
+    views of it (``out(name, shape)``), the bucket is all-reduced in place - no packing copy (``torch.cat``) and no per-step allocation,
+    and the optimizer's pointer table never changes.  The layout is discovered during the first backward (``out`` returns None there and
+    the caller allocates as before); from the second step on the views are served - each name at most ONCE between two ``begin_step()``
+    calls: a second backward through the same module within one step (two fusion calls, a module used outside the trainer) gets None and
+    allocates, so gradients that autograd already holds as views of the buffer are never overwritten."""
+
+    def __init__(self, align: int = 64):
+        self._served = set()
+        self.layout: Dict[str, tuple] = {}        # name -> (offset, shape)
+        self.size = 0
+        self.flat: Optional[torch.Tensor] = None
+        self.align = align                        # elements: every view starts 256-byte aligned (vector loads of the kernels that read it)
+        self._device = None
+
+    def out(self, name: str, shape, device) -> Optional[torch.Tensor]:
+        shape = tuple(int(x) for x in shape)
+        hit = self.layout.get(name)
+        if hit is None or hit[1] != shape:
+            if self.flat is not None:             # a new tensor after the layout was frozen (freeze policy changed): start over
+                self.flat, self.layout, self.size = None, {}, 0
+            n = 1
+            for x in shape:
+                n *= x
+            self.layout[name] = (self.size, shape)
+            self.size += (n + self.align - 1) // self.align * self.align
+            self._device = device
+            return None
+        if self.flat is None or name in self._served:
+            return None
+        self._served.add(name)
+        off, shp = hit
+        n = 1
+        for x in shp:
+            n *= x
+        return self.flat[off:off + n].view(shp)
+
+    def begin_step(self) -> None:
+        self._served.clear()
+
+    def finalize(self) -> None:
+        """End of a backward in which the layout was (re)discovered: allocate the buffer; the NEXT backward writes into it."""
+        if self.flat is None and self.size > 0:
+            self.flat = torch.zeros(self.size, dtype=torch.float32, device=self._device)
+
+    def owns(self, t: torch.Tensor) -> bool:
+        if self.flat is None or t is None or t.device != self.flat.device or t.dtype != torch.float32:
+            return False
+        lo = self.flat.data_ptr()
+        return lo <= t.data_ptr() and t.data_ptr() + t.numel() * 4 <= lo + self.flat.numel() * 4
+
+
 class GradBucketReducer:
     def __init__(self, group=None, side_stream: bool = True, always_collective: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # issue the collectives even in a group of one rank (rehearsal of the RCCL path on a one-GPU box: same calls, same streams)
         self.always = always_collective and dist.is_initialized()
-        self.pending = []            # (work, flat, event)
+        self.pending = []            # (work, flat, stream)
         self.stream: Optional[torch.cuda.Stream] = None
         self._use_side = side_stream
+        # bookkeeping for the N > 1 bench line: buckets issued without / with a packing copy, their sizes, exposed wait on the GPU timeline
+        self.flat_reduces = 0
+        self.cat_reduces = 0
+        self.bucket_bytes: List[int] = []         # of the current step (cleared by wait())
+        self.last_bucket_bytes: List[int] = []
+        self.timing = False
+        self._wait_events = []                    # (before, after) event pairs around the join of the side stream
 
     def _side(self, dev):
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=dev)
         return self.stream
 
-    def reduce_async(self, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
-        """Pack ``tensors`` into one flat bucket, start its all-reduce (SUM), return views of the bucket that alias
-        the reduced values once ``wait()`` has been called."""
-        tensors = [t for t in tensors if t is not None]
-        if not tensors:
-            return []
-        flat = torch.cat([t.reshape(-1) for t in tensors])
-        views, off = [], 0
-        for t in tensors:
-            views.append(flat[off:off + t.numel()].view(t.shape))
-            off += t.numel()
+    def _issue(self, flat: torch.Tensor) -> None:
+        self.bucket_bytes.append(flat.numel() * flat.element_size())
         if self.world > 1 or self.always:
             if flat.is_cuda and self._use_side:
                 s = self._side(flat.device)
@@ -52,20 +103,51 @@ class GradBucketReducer:
             else:
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self.pending.append((work, flat, None))
+
+    def reduce_flat(self, arena: GradArena) -> None:
+        """All-reduce (SUM) of a bucket whose gradients already live in one flat buffer: in place, nothing is copied."""
+        self.flat_reduces += 1
+        self._issue(arena.flat)
+
+    def reduce_async(self, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Pack ``tensors`` into one flat bucket, start its all-reduce (SUM), return views of the bucket that alias
+        the reduced values once ``wait()`` has been called.  (Buckets whose layout is not known yet: the first step.)"""
+        tensors = [t for t in tensors if t is not None]
+        if not tensors:
+            return []
+        self.cat_reduces += 1
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        views, off = [], 0
+        for t in tensors:
+            views.append(flat[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+        self._issue(flat)
         return views
 
     def wait(self) -> None:
-        import os, time
-        timing = os.environ.get("AVAMD_DP_TIMING") == "1"
+        dev = None
         for work, flat, s in self.pending:
-            t0 = time.perf_counter()
+            if flat.is_cuda:
+                dev = flat.device
+        ev0 = ev1 = None
+        if self.timing and dev is not None:
+            ev0 = torch.cuda.Event(enable_timing=True); ev0.record(torch.cuda.current_stream(dev))
+        for work, flat, s in self.pending:
             work.wait()
-            if timing:
-                import sys
-                print(f"[dp] bucket {flat.numel() * flat.element_size() / 1e6:8.1f} MB waited {1e3 * (time.perf_counter() - t0):8.1f} ms", file=sys.stderr, flush=True)
             if s is not None:
                 torch.cuda.current_stream(flat.device).wait_stream(s)
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True); ev1.record(torch.cuda.current_stream(dev))
+            self._wait_events.append((ev0, ev1))
         self.pending.clear()
+        if self.bucket_bytes:
+            self.last_bucket_bytes, self.bucket_bytes = self.bucket_bytes, []
+
+    def exposed_ms(self) -> List[float]:
+        """Per joined step: time the main stream spent waiting for the gradient exchange at the join (after a device synchronisation)."""
+        out = [a.elapsed_time(b) for a, b in self._wait_events]
+        self._wait_events = []
+        return out
 
 
 def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:

@@ -36,6 +36,20 @@ def _worker(rank, world, port, q):
         want = sum(torch.from_numpy(gather[r][i]) for r in range(world))
         assert torch.allclose(v, want, atol=1e-6), (rank, i)
         assert torch.allclose(v / world, want / world)
+    # a bucket that already lives in one flat buffer (GradArena): reduced in place, views keep aliasing it, served once per step
+    ar = dp.GradArena(align=4)
+    assert ar.out("w", (3, 5), "cpu") is None and ar.out("b", (7,), "cpu") is None      # first backward: layout discovery
+    ar.finalize(); ar.begin_step()
+    w, b = ar.out("w", (3, 5), "cpu"), ar.out("b", (7,), "cpu")
+    assert w is not None and b is not None and ar.owns(w) and ar.owns(b) and not ar.owns(torch.zeros(3))
+    assert ar.out("w", (3, 5), "cpu") is None                                              # second request in the same step: not served
+    w.copy_(torch.full((3, 5), float(rank + 1))); b.copy_(torch.arange(7.0) * (rank + 1))
+    n_cat = red.cat_reduces
+    red.reduce_flat(ar); red.wait()
+    assert red.cat_reduces == n_cat and red.flat_reduces == 1
+    assert torch.equal(w, torch.full((3, 5), 3.0)) and torch.equal(b, torch.arange(7.0) * 3)
+    ar.begin_step()
+    assert ar.out("w", (3, 5), "cpu").data_ptr() == w.data_ptr()                           # stable addresses from step to step
     batch = synth.make_batch(4, 0.1, seed=3)
     sh = dp.shard_batch(batch, rank, world)
     assert sh["audio"].shape[0] == 2 and torch.equal(sh["audio"], batch["audio"][rank * 2:(rank + 1) * 2])

@@ -161,3 +161,56 @@ def test_forty_steps_tiny_config_layerdrop_half(precision, loss_scaling):
     steps = sorted({st["step"] for st in t.optimizer.state.values() if "step" in st}) if not loss_scaling else None
     if steps is not None:
         assert len(steps) > 1 and steps[-1] == 40                    # per-parameter counts really diverged, the head never skipped
+
+
+def test_config5_batch_128_loss_scaling_as_executed():
+    """BASELINE.json configs[4] in its stated mode: batch 128 x 4 s, contrastive loss on, "fp16 + fp32 master" = the reference's
+    GradScaler law (model/trainer.py:40,65,121-123; bf16 MFMA operands here, fp32 master weights), HF-default regularisers, two audio
+    passes.  8 steps with an overflow injected into one gradient at steps 2 and 5: the scale trajectory equals torch.amp.GradScaler's on
+    the same found-inf pattern, an overflowing step leaves every parameter untouched and advances no step counter, clean steps update."""
+    import bench
+    optim = pkg("optim")
+    t, batch, cfg = bench.build_trainer(128, 4.0, "bf16", "cuda:0", loss_scaling=True)
+    t.scaler = optim.AvGradScaler(init_scale=65536.0, growth_interval=3, device="cuda:0")       # short interval: growth is exercised too
+    t.audio_encoder.model.cfg.update(bench.HF_REGULARIZERS)
+    torch.manual_seed(77); np.random.seed(77)
+    # torch's scaler driven by the same found-inf pattern (a one-element dummy parameter)
+    dummy = torch.zeros(1, device="cuda", requires_grad=True)
+    o_ref = torch.optim.SGD([dummy], lr=0.0)
+    s_ref = torch.amp.GradScaler("cuda", init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    named = [(n, p) for mod in (t.audio_encoder.model, t.fusion_module, t.decoder1) for n, p in mod.named_parameters() if p.requires_grad]
+    probe = dict(named)["encoder.layers.8.feed_forward.output_dense.weight"]
+    inject_at = (2, 5)
+    taken = 0
+    for step in range(8):
+        sc_ref = float(s_ref.scale(torch.ones((), device="cuda")))
+        assert t.scaler.get_scale() == sc_ref, (step, t.scaler.get_scale(), sc_ref)
+        t.optimizer.zero_grad(set_to_none=True)
+        out = t.forward_losses(batch)
+        assert np.isfinite(float(out["total"].detach())), step
+        t.scaler.scale(out["total"]).backward()
+        with_grad = [p for _, p in named if p.grad is not None]
+        assert all(bool(torch.isfinite(p.grad).all()) for p in with_grad[:8])
+        g0 = float(probe.grad.abs().max()) if probe.grad is not None else None
+        if g0 is not None:
+            assert g0 > 0.0                                          # the scaled gradients are real (scale folded out only inside Adam)
+        dummy.grad = torch.ones(1, device="cuda")
+        if step in inject_at:
+            with_grad[-1].grad.view(-1)[11] = float("inf")
+            dummy.grad[0] = float("inf")
+        before = [p.detach().clone() for p in with_grad]
+        t.scaler.step(t.optimizer); t.scaler.update()
+        s_ref.step(o_ref); s_ref.update()
+        changed = [not torch.equal(p.detach(), b) for p, b in zip(with_grad, before)]
+        if step in inject_at:
+            assert not any(changed), step                            # skipped: nothing moved
+        else:
+            assert sum(changed) >= len(changed) - 2, step          # (a tensor whose gradient is exactly zero would not move)
+            taken += 1
+        assert t.scaler.steps_taken() == taken
+    assert t.scaler.get_scale() == s_ref.get_scale()
+    t.optimizer.sync_steps(t.scaler)
+    counts = sorted({st["step"] for st in t.optimizer.state.values() if "step" in st})
+    assert counts[-1] == taken and t.optimizer.fused_launches == 8
+    sums = torch.stack([p.detach().float().sum() for _, p in named])
+    assert bool(torch.isfinite(sums).all())
