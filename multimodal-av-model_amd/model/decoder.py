@@ -32,9 +32,9 @@ class _HeadFn(torch.autograd.Function):
         d2 = dlogits.view(-1, V)
         dx = ops.matmul_nn(d2, wt, out_dtype=torch.float32).view(xt.shape) if fctx.needs_input_grad[0] else None
         ar, dev = fctx.arena, d2.device
-        A = (lambda n, shp: ar.out("decoder." + n, shp, dev)) if ar is not None else (lambda n, shp: None)
+        A = (lambda n, shp, vec=False: ar.out("decoder." + n, shp, dev, vec)) if ar is not None else (lambda n, shp, vec=False: None)
         dw = ops.matmul_tn(d2, xt.view(-1, D), out=A("weight", (V, D))) if fctx.needs_input_grad[1] else None
-        db = ops.colsum(d2, out=A("bias", (V,))) if fctx.needs_input_grad[2] else None
+        db = ops.colsum_into(d2, A("bias", (V,), True)) if fctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
 
 

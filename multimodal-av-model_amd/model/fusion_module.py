@@ -100,7 +100,7 @@ def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: D
         dg2 = dgates.view(M, 8 * H)
         in_f = inp.shape[-1]
         dwih = ops.matmul_tn(dg2, inp.view(M, in_f), out=A(f"lstm.dwih{layer}", (8 * H, in_f), dev))     # [8H, in]
-        db = ops.colsum(dg2, out=A(f"lstm.db{layer}", (8 * H,), dev))                    # [8H]
+        db = ops.colsum_into(dg2, A(f"lstm.db{layer}", (8 * H,), dev, True))             # [8H]
         n = c["names"]
         grads["temporal_model." + n[0]] = dwih[:4 * H]
         grads["temporal_model." + n[1]] = dwih[4 * H:]
@@ -193,11 +193,11 @@ class _FusionFn(torch.autograd.Function):
         dev = dout.device
         A = mod._grad_out
         g["fusion_proj.weight"] = ops.matmul_tn(df2, s["a2v"].view(M, E), out=A("fusion_proj.weight", (E, E), dev))
-        g["fusion_proj.bias"] = ops.colsum(df2, out=A("fusion_proj.bias", (E,), dev))
+        g["fusion_proj.bias"] = ops.colsum_into(df2, A("fusion_proj.bias", (E,), dev, True))
         da2v = ops.matmul_nn(df2, c(mod.fusion_proj.weight))
         mha = mod.cross_attn_audio
         g["cross_attn_audio.out_proj.weight"] = ops.matmul_tn(da2v, s["o"].view(M, E), out=A("xa.out_proj.weight", (E, E), dev))
-        g["cross_attn_audio.out_proj.bias"] = ops.colsum(da2v, out=A("xa.out_proj.bias", (E,), dev))
+        g["cross_attn_audio.out_proj.bias"] = ops.colsum_into(da2v, A("xa.out_proj.bias", (E,), dev, True))
         do = ops.matmul_nn(da2v, c(mha.out_proj.weight)).view(B, Tv, nh, hd)
         q, kv = s["q"], s["kv"]
         if FUSED_XATTN and dtype == torch.bfloat16 and E == 512 and nh == 4 and Tv <= 112:
@@ -213,17 +213,18 @@ class _FusionFn(torch.autograd.Function):
         ops.matmul_tn(dq2, s["a"].view(M, E), out=dWin[:E])
         ops.matmul_tn(dkv2, s["v"].view(M, E), out=dWin[E:])
         g["cross_attn_audio.in_proj_weight"] = dWin
-        dbin = A("xa.in_proj_bias", (3 * E,), dev)
+        dbin = A("xa.in_proj_bias", (3 * E,), dev, True)
+        zeroed = dbin is not None
         if dbin is None:
             dbin = torch.empty(3 * E, dtype=torch.float32, device=dev)
-        ops.colsum(dq2, out=dbin[:E]); ops.colsum(dkv2, out=dbin[E:])
+        ops.colsum(dq2, out=dbin[:E], accumulate=zeroed); ops.colsum(dkv2, out=dbin[E:], accumulate=zeroed)
         g["cross_attn_audio.in_proj_bias"] = dbin
         da = ops.matmul_nn(dq2, Win[:E])
         dv = ops.matmul_nn(dkv2, Win[E:])
         g["audio_proj.weight"] = ops.matmul_tn(da, s["a_in_t"].view(M, Da), out=A("audio_proj.weight", (E, Da), dev))
-        g["audio_proj.bias"] = ops.colsum(da, out=A("audio_proj.bias", (E,), dev))
+        g["audio_proj.bias"] = ops.colsum_into(da, A("audio_proj.bias", (E,), dev, True))
         g["visual_proj.weight"] = ops.matmul_tn(dv, s["vis_t"].view(M, Dv), out=A("visual_proj.weight", (E, Dv), dev))
-        g["visual_proj.bias"] = ops.colsum(dv, out=A("visual_proj.bias", (E,), dev))
+        g["visual_proj.bias"] = ops.colsum_into(dv, A("visual_proj.bias", (E,), dev, True))
         d_audio = d_visual = None
         if fctx.need_audio:
             da_in = ops.matmul_nn(da, c(mod.audio_proj.weight), out_dtype=torch.float32)       # [M, Da]
@@ -280,9 +281,10 @@ class CrossAttentionFusion(nn.Module):
             raise RuntimeError("persistent LSTM kernel: inter-workgroup wait timed out (the step that launched it is invalid); "
                                "AVAMD_LSTM_PERSISTENT=0 selects the per-step kernels (e.g. on a GPU shared with other processes)")
 
-    def _grad_out(self, name: str, shape, device):
-        """View of the flat gradient bucket for this gradient, or None (no bucket / layout not known yet / already written this step)."""
-        return self.grad_arena.out("fusion." + name, shape, device) if self.grad_arena is not None else None
+    def _grad_out(self, name: str, shape, device, vec: bool = False):
+        """View of the flat gradient bucket for this gradient, or None (no bucket / layout not known yet / already written this step).
+        ``vec``: a zeroed view of the bucket's vector zone, to be accumulated into."""
+        return self.grad_arena.out("fusion." + name, shape, device, vec) if self.grad_arena is not None else None
 
     def cparam(self, p: Tensor, dtype) -> Tensor:
         if dtype == torch.float32:

@@ -289,11 +289,26 @@ class Wav2Vec2ModelHIP(nn.Module):
         B, T, C = feats.shape
         klen = keep = None
         n_host = None
+        want_sm = tm and sc["mask_time_prob"] > 0 and cfg.get("apply_spec_augment", True)
+        smt = None
         if attention_mask is not None and valid_lengths is not None:
+            # host-side metadata of the pass in ONE upload: key lengths (int32), frame keep mask, SpecAugment time mask (hf:1272-1296, drawn
+            # from numpy's global RNG as HF does - before the feature-axis mask, which keeps HF's draw order)
             import numpy as np
             n_host = np.asarray([int(conv_out_lengths(cfg, int(v))) for v in valid_lengths], dtype=np.int64)
-            klen = ops.h2d_async(np.clip(n_host, 1, T).astype(np.int32), dev)
-            keep = ops.h2d_async((np.arange(T)[None, :] < n_host[:, None]).astype(np.uint8), dev)
+            o_keep = (4 * B + 15) // 16 * 16
+            o_sm = o_keep + (B * T + 15) // 16 * 16
+            pack = np.zeros(o_sm + (B * T if want_sm else 0), dtype=np.uint8)
+            pack[:4 * B] = np.clip(n_host, 1, T).astype(np.int32).view(np.uint8)
+            pack[o_keep:o_keep + B * T] = (np.arange(T)[None, :] < n_host[:, None]).astype(np.uint8).reshape(-1)
+            if want_sm:
+                sm = specaugment_mask(B, T, sc["mask_time_prob"], sc["mask_time_length"], n_host.tolist(), sc["mask_time_min_masks"])
+                pack[o_sm:o_sm + B * T] = sm.astype(np.uint8).reshape(-1)
+            dpack = ops.h2d_async(pack, dev)
+            klen = dpack[:4 * B].view(torch.int32)
+            keep = dpack[o_keep:o_keep + B * T].view(B, T)
+            if want_sm:
+                smt = dpack[o_sm:o_sm + B * T].view(B, T)
         elif attention_mask is not None:
             n = conv_out_lengths(cfg, attention_mask.long().sum(-1))
             klen = n.clamp(min=1, max=T).to(torch.int32)
@@ -304,10 +319,11 @@ class Wav2Vec2ModelHIP(nn.Module):
                        out_dtype=torch.float32)
         if fp_p > 0:
             h = ops.cast_dropout(h, torch.float32, (fp_p, seed, S_FEATPROJ))             # hf:433
-        if tm and sc["mask_time_prob"] > 0 and cfg.get("apply_spec_augment", True):      # hf:1272-1296 (host numpy RNG, as HF)
-            lengths = (n_host.tolist() if n_host is not None else n.tolist()) if attention_mask is not None else [T] * B
-            sm = specaugment_mask(B, T, sc["mask_time_prob"], sc["mask_time_length"], lengths, sc["mask_time_min_masks"])
-            smt = ops.h2d_async(sm.astype("uint8"), dev)
+        if want_sm:                                                                      # hf:1272-1296 (host numpy RNG, as HF)
+            if smt is None:
+                lengths = n.tolist() if attention_mask is not None else [T] * B
+                sm = specaugment_mask(B, T, sc["mask_time_prob"], sc["mask_time_length"], lengths, sc["mask_time_min_masks"])
+                smt = ops.h2d_async(sm.astype("uint8"), dev)
             L.check(L.lib().av_overwrite_rows(ops.ptr(h), ops.dt(h), ops.ptr(smt), ops.ptr(self.P("masked_spec_embed").data), B * T, Hd,
                                               ops.stream()), "av_overwrite_rows")
         if tm and sc["mask_feature_prob"] > 0 and cfg.get("apply_spec_augment", True):   # hf:1298-1316: drawn AFTER the time mask, same numpy RNG
@@ -360,12 +376,12 @@ class Wav2Vec2ModelHIP(nn.Module):
             amask_evt = (amask_evts, last_evt)
             for m in amasks.values():
                 m.record_stream(main)
-        mid = torch.zeros_like(h) if nl >= 10 else None
+        mid = torch.empty_like(h) if nl >= 10 else None
         saved = [None] * nl
         scale = hd ** -0.5
         for li in range(nl):
             if mid is not None and 6 <= li <= 9:
-                ops.axpby(0.25, h, 1.0, mid)                                             # model/encoder.py:97-99
+                ops.axpby(0.25, h, 1.0 if li > 6 else 0.0, mid)                          # model/encoder.py:97-99 (the first term writes: no zero fill)
             p = f"encoder.layers.{li}."
             keep_ctx = save and li >= first
             if dropped[li]:                                                              # LayerDrop (hf:774-789): identity layer
@@ -532,7 +548,11 @@ class Wav2Vec2ModelHIP(nn.Module):
             if key in grads:
                 ops.colsum(dy, out=grads[key], accumulate=True)
             else:
-                grads[key] = ops.colsum(dy, out=ar.out(key, (dy.shape[-1],), dev_))
+                grads[key] = ops.colsum_into(dy, ar.out(key, (dy.shape[-1],), dev_, vec=True))
+
+        def gb_target(key):                                          # packed LayerNorm gradients: an earlier pass's tensor, else a zeroed bucket view
+            hit = grads.get(key)
+            return hit if hit is not None else ar.out(key, (2 * Hd,), dev_, vec=True)
 
         dh3 = dh
         dh3_t = dh_lp if (fuse_lp and dh_lp is not None) else ops.cast_dropout(dh3, dtype, (hd_p, seed, li * 8 + 2))   # FFN-output dropout mask
@@ -553,8 +573,7 @@ class Wav2Vec2ModelHIP(nn.Module):
         ln2 = p + "final_layer_norm."
         r = ops.layernorm_bwd(s["h2"], dx2.view(B, T, Hd), self.P(ln2 + "weight").data, s["mu2"], s["rs2"], dres=dh3,
                               want_param_grads=tr, lp_copy=fuse_lp, lp_drop=(hd_p, seed, li * 8 + 0),   # consumer: this layer's attention-output dropout
-                              gb_acc=grads.get(ln2 + "_gb") if tr else None, packed_gb=True,
-                              gb_out=ar.out(ln2 + "_gb", (2 * Hd,), dev_) if (tr and (ln2 + "_gb") not in grads) else None)
+                              gb_acc=gb_target(ln2 + "_gb") if tr else None, packed_gb=True)
         dh2_lp = None
         if fuse_lp:
             r, dh2_lp = r[:-1], r[-1]
@@ -586,8 +605,7 @@ class Wav2Vec2ModelHIP(nn.Module):
         ln1 = p + "layer_norm."
         r = ops.layernorm_bwd(s["h"], dx1.view(B, T, Hd), self.P(ln1 + "weight").data, s["mu1"], s["rs1"], dres=dh2,
                               want_param_grads=tr, lp_copy=lp_ok, lp_drop=(hd_p, seed, lower * 8 + 2),
-                              gb_acc=grads.get(ln1 + "_gb") if tr else None, packed_gb=True,
-                              gb_out=ar.out(ln1 + "_gb", (2 * Hd,), dev_) if (tr and (ln1 + "_gb") not in grads) else None)
+                              gb_acc=gb_target(ln1 + "_gb") if tr else None, packed_gb=True)
         dh_lp = None
         if lp_ok:
             r, dh_lp = r[:-1], r[-1]

@@ -294,11 +294,11 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, *, out_dtype: torch.dt
 
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
                   want_param_grads: bool = False, lp_copy: bool = False, lp_drop: Optional[tuple] = None, gb_acc: Optional[Tensor] = None,
-                  packed_gb: bool = False, gb_out: Optional[Tensor] = None):
+                  packed_gb: bool = False):
     """dx (fp32) [, dgamma, dbeta]; with ``lp_copy`` the last element returned is a bf16 copy of dx written by the same kernel;
     ``lp_drop`` = (p, seed, stream id) makes that copy dx o dropout-mask / (1 - p).  ``gb_acc`` (a [2 cols] tensor from an earlier call) /
-    ``packed_gb``: the parameter gradients come back as ONE packed tensor [dgamma | dbeta], accumulated into ``gb_acc`` when given
-    (``gb_out``: written there instead of a fresh tensor - a view of a gradient bucket)."""
+    ``packed_gb``: the parameter gradients come back as ONE packed tensor [dgamma | dbeta], accumulated into ``gb_acc`` when given (an
+    earlier pass's tensor, or a zeroed view of a gradient bucket)."""
     cols = x.shape[-1]
     rows = x.numel() // cols
     assert x.is_contiguous() and dy.is_contiguous()
@@ -319,7 +319,7 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
             gb = colsum(part, out=gb_acc, accumulate=True)
             res = (dx, gb)
         elif packed_gb:
-            res = (dx, colsum(part, out=gb_out))
+            res = (dx, colsum(part))
         else:
             gb = colsum(part)
             res = (dx, gb[:cols], gb[cols:])
@@ -351,6 +351,11 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
         accumulate = False
     L.check(L.lib().av_colsum(ptr(x), dt(x), ptr(out), rows, cols, cols, int(accumulate), stream()), "av_colsum")
     return out
+
+
+def colsum_into(x: Tensor, zeroed_view: Optional[Tensor]) -> Tensor:
+    """Column sums accumulated into a pre-zeroed view of a gradient bucket (no clear launch), or into a fresh tensor when there is none."""
+    return colsum(x, out=zeroed_view, accumulate=True) if zeroed_view is not None else colsum(x)
 
 
 def cast(x: Tensor, dtype: torch.dtype) -> Tensor:

@@ -21,45 +21,53 @@ class GradArena:
     and the optimizer's pointer table never changes.  The layout is discovered during the first backward (``out`` returns None there and
     the caller allocates as before); from the second step on the views are served - each name at most ONCE between two ``begin_step()``
     calls: a second backward through the same module within one step (two fusion calls, a module used outside the trainer) gets None and
-    allocates, so gradients that autograd already holds as views of the buffer are never overwritten."""
+    allocates, so gradients that autograd already holds as views of the buffer are never overwritten.
+    Vector-shaped gradients (biases, LayerNorm gains: column sums that accumulate with atomics) live in a zone of their own at the front of
+    the buffer which ``begin_step()`` clears with ONE fill; their views come back zeroed and are accumulated into (a separate clear per
+    column sum was 38 fill launches per step)."""
 
     def __init__(self, align: int = 64):
         self._served = set()
-        self.layout: Dict[str, tuple] = {}        # name -> (offset, shape)
-        self.size = 0
+        self.layout: Dict[str, tuple] = {}        # name -> (zone, offset inside the zone, shape); zone 0 = vectors (zeroed per step), 1 = matrices
+        self.zone_size = [0, 0]
         self.flat: Optional[torch.Tensor] = None
         self.align = align                        # elements: every view starts 256-byte aligned (vector loads of the kernels that read it)
         self._device = None
 
-    def out(self, name: str, shape, device) -> Optional[torch.Tensor]:
+    @staticmethod
+    def _numel(shape) -> int:
+        n = 1
+        for x in shape:
+            n *= x
+        return n
+
+    def out(self, name: str, shape, device, vec: bool = False) -> Optional[torch.Tensor]:
+        """``vec``: the view lies in the per-step-zeroed zone: the caller ACCUMULATES into it."""
         shape = tuple(int(x) for x in shape)
+        zone = 0 if vec else 1
         hit = self.layout.get(name)
-        if hit is None or hit[1] != shape:
+        if hit is None or hit[2] != shape or hit[0] != zone:
             if self.flat is not None:             # a new tensor after the layout was frozen (freeze policy changed): start over
-                self.flat, self.layout, self.size = None, {}, 0
-            n = 1
-            for x in shape:
-                n *= x
-            self.layout[name] = (self.size, shape)
-            self.size += (n + self.align - 1) // self.align * self.align
+                self.flat, self.layout, self.zone_size = None, {}, [0, 0]
+            self.layout[name] = (zone, self.zone_size[zone], shape)
+            self.zone_size[zone] += (self._numel(shape) + self.align - 1) // self.align * self.align
             self._device = device
             return None
         if self.flat is None or name in self._served:
             return None
         self._served.add(name)
-        off, shp = hit
-        n = 1
-        for x in shp:
-            n *= x
-        return self.flat[off:off + n].view(shp)
+        off = hit[1] + (self.zone_size[0] if zone == 1 else 0)
+        return self.flat[off:off + self._numel(shape)].view(shape)
 
     def begin_step(self) -> None:
         self._served.clear()
+        if self.flat is not None and self.zone_size[0] > 0:
+            self.flat[:self.zone_size[0]].zero_()
 
     def finalize(self) -> None:
         """End of a backward in which the layout was (re)discovered: allocate the buffer; the NEXT backward writes into it."""
-        if self.flat is None and self.size > 0:
-            self.flat = torch.zeros(self.size, dtype=torch.float32, device=self._device)
+        if self.flat is None and sum(self.zone_size) > 0:
+            self.flat = torch.zeros(sum(self.zone_size), dtype=torch.float32, device=self._device)
 
     def owns(self, t: torch.Tensor) -> bool:
         if self.flat is None or t is None or t.device != self.flat.device or t.dtype != torch.float32:

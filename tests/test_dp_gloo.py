@@ -50,6 +50,14 @@ def _worker(rank, world, port, q):
     assert torch.equal(w, torch.full((3, 5), 3.0)) and torch.equal(b, torch.arange(7.0) * 3)
     ar.begin_step()
     assert ar.out("w", (3, 5), "cpu").data_ptr() == w.data_ptr()                           # stable addresses from step to step
+    # vector zone: zeroed by begin_step, accumulated into
+    ar2 = dp.GradArena(align=4)
+    assert ar2.out("bias", (6,), "cpu", vec=True) is None and ar2.out("w", (2, 3), "cpu") is None
+    ar2.finalize(); ar2.begin_step()
+    bv, wv = ar2.out("bias", (6,), "cpu", vec=True), ar2.out("w", (2, 3), "cpu")
+    bv.add_(5.0); wv.fill_(7.0)
+    ar2.begin_step()
+    assert float(ar2.out("bias", (6,), "cpu", vec=True).abs().sum()) == 0.0 and float(ar2.out("w", (2, 3), "cpu").sum()) == 42.0
     batch = synth.make_batch(4, 0.1, seed=3)
     sh = dp.shard_batch(batch, rank, world)
     assert sh["audio"].shape[0] == 2 and torch.equal(sh["audio"], batch["audio"][rank * 2:(rank + 1) * 2])
