@@ -80,6 +80,13 @@ typedef struct av_gemm_args {
      * Only with both operands k-major (a_mode 1, b_mode 1, bf16 fast kernel): dW = dY^T X with few output tiles; the
      * partial products C + z*sC are summed with av_sum_slices. */
     int k_total;
+    /* position-major pixel order for 2-D implicit-im2col products (a_mode 2, bf16 fast path).  Images are taken in blocks of cNF (the
+     * image count must be a multiple of it); inside a block the rows are ordered [pixel position][image of the block]: image q's pixel
+     * `pos` of a P-pixel map is row ((q / cNF) * P + pos) * cNF + q % cNF.  cPM bit 0: the INPUT is in that order (P = cH * cW), bit 1:
+     * the OUTPUT is (P = cOh * cOw).  With cNF a multiple of the row tile (256) every row tile lies at one output position, so filter taps
+     * that fall outside the image for that position are skipped as whole K-tiles (3 x 3 images under a 3 x 3 filter, model/encoder.py:36
+     * layer4: 49 of 81 taps do work), and consecutive row tiles re-read the same images' pixels from L2.  0 / 0 = frame-major order. */
+    int cNF, cPM;
 } av_gemm_args;
 int av_gemm(const av_gemm_args* args, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + alpha * sum_s parts[s*stride + i], i < n (fp32): the split-K partials of av_gemm */
@@ -231,7 +238,7 @@ int av_bn_act(const void* x, const float* scale, const float* shift, const void*
               const float* rshift, const float* slope, void* out, int dtype, long long n, int C, void* stream);
 int av_bn_prelu_maxpool(const void* x, const float* scale, const float* shift, const float* slope, void* out, int dtype,
                         long long N, int H, int W, int C, void* stream);
-int av_avgpool(const void* x, int dtype, float* out, long long N, int HW, int C, void* stream);
+int av_avgpool(const void* x, int dtype, float* out, long long N, int HW, int C, int pm_block, void* stream);   /* pm_block: 0 = frame-major, else images per position-major block (av_gemm_args.cNF) */
 
 /* ---- loss / optimizer side (contrastive.py:8-44; torch.optim.Adam, model/trainer.py:34-39) ------------------ */
 int av_l2norm_fwd(const float* x, float* y, float* nrm, long long rows, int cols, float eps, void* stream);

@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
         ("cOh", i32), ("cOw", i32),
         ("batch_inner", i32), ("oA", ll), ("oB", ll), ("oC", ll),
         ("drop_p", f32), ("drop_stream", C.c_uint), ("drop_seed", C.c_ulonglong),
-        ("k_total", i32),
+        ("k_total", i32), ("cNF", i32), ("cPM", i32),
     ]
 
 
@@ -81,7 +81,7 @@ SIGNATURES = {
     "av_bn_finalize": [vp, i32, ll, vp, vp, vp, vp, f32, f32, i32, vp, vp, i32, vp, i32, vp],
     "av_bn_act": [vp, vp, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp],
     "av_bn_prelu_maxpool": [vp, vp, vp, vp, vp, i32, ll, i32, i32, i32, vp],
-    "av_avgpool": [vp, i32, vp, ll, i32, i32, vp],
+    "av_avgpool": [vp, i32, vp, ll, i32, i32, i32, vp],
     "av_l2norm_fwd": [vp, vp, vp, ll, i32, f32, vp],
     "av_l2norm_bwd": [vp, vp, vp, vp, ll, i32, f32, vp],
     "av_lse_rows": [vp, vp, vp, ll, i32, i32, vp],

@@ -407,6 +407,7 @@ extern "C" int av_gemm(const av_gemm_args* a, void* stream) {
         const int fr = av_gemm_fast_try(p, st);
         if (fr >= 0) return fr;
     }
+    AV_CHECK(p.cPM == 0, "av_gemm: position-major pixel order (cPM) needs the bf16 fast path (2-D convolution, Cin a multiple of 64, one batch)");
     AV_CHECK(p.k_total == 0, "av_gemm: split-K (k_total) needs the bf16 fast path with both operands k-major (a_mode 1, b_mode 1, M, N multiples of 8 and > 64)");
     const bool wide = p.N > 64;
     if (p.in_dtype == AV_F32) {

@@ -93,6 +93,53 @@ __device__ __forceinline__ bf16x8 kmajor_frag(const char* tile, const KmOff& o, 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Position-major pixel order (av_gemm_args.cNF / cPM): decode an output row and address an input pixel.
+// Blocked: images are taken in blocks of cNF; inside a block the order is [position][image of the block], i.e. image q's pixel `pos` of a P-pixel
+// map is row ((q / cNF) * P + pos) * cNF + q % cNF.  A row tile then lies at ONE position, and consecutive row tiles are the neighbouring
+// positions of the SAME images: their input windows overlap and are re-read from this XCD's L2 (with one block = the whole batch every tap
+// of every tile fetched 256 fresh pixel rows from beyond L2 and the skipped taps bought only 6 %).
+__device__ __forceinline__ void conv_decode(const av_gemm_args& p, int m, int& q, int& oy, int& ox) {
+    if (p.cPM & 2) {
+        const int per = p.cOh * p.cOw * p.cNF, blk = m / per, rem = m - blk * per, pos = rem / p.cNF;
+        q = blk * p.cNF + (rem - pos * p.cNF); oy = pos / p.cOw; ox = pos - oy * p.cOw;
+    } else { ox = m % p.cOw; int t = m / p.cOw; oy = t % p.cOh; q = t / p.cOh; }
+}
+__device__ __forceinline__ long long conv_pixel(const av_gemm_args& p, int q, int iy, int ix) {        // row index of input pixel (q, iy, ix)
+    if (p.cPM & 1) { const int blk = q / p.cNF; return ((long long)blk * (p.cH * p.cW) + iy * p.cW + ix) * p.cNF + (q - blk * p.cNF); }
+    return ((long long)q * p.cH + iy) * p.cW + ix;
+}
+// K-tile sequence of a row tile: all rows of [m0, m0 + rows) share one output position (position-major output, tile inside one position's
+// block of cNF rows) => the taps outside the image for that position are dropped: seq holds the remaining tap indices (4 bits each).
+// Otherwise every tap stays.  K-tile t covers tap seq[t >> sh], channels 64 (t & (cpt - 1)) ..; cpt = Cin / 64 = 1 << sh.
+struct TapSeq { unsigned long long seq; int ntap, sh; };
+__device__ __forceinline__ TapSeq tap_seq(const av_gemm_args& p, int m0, int rows) {
+    TapSeq ts;
+    const int ntaps = p.cKh * p.cKw, cpt = p.cCin >> 6;
+    ts.sh = 31 - __builtin_clz(cpt);
+    unsigned mask = ntaps >= 32 ? 0xffffffffu : ((1u << ntaps) - 1u);
+    int mlast = m0 + rows - 1;
+    if (mlast > p.M - 1) mlast = p.M - 1;
+    if ((p.cPM & 2) && ntaps <= 16 && (1 << ts.sh) == cpt && m0 / p.cNF == mlast / p.cNF) {
+        const int pos = (m0 / p.cNF) % (p.cOh * p.cOw), oy = pos / p.cOw, ox = pos - oy * p.cOw;
+        const int iy0 = oy * p.cSh - p.cPh, ix0 = ox * p.cSw - p.cPw;
+        mask = 0u;
+        for (int ky = 0; ky < p.cKh; ++ky)
+            for (int kx = 0; kx < p.cKw; ++kx)
+                if (iy0 + ky >= 0 && iy0 + ky < p.cH && ix0 + kx >= 0 && ix0 + kx < p.cW) mask |= 1u << (ky * p.cKw + kx);
+    }
+    ts.seq = 0ull; ts.ntap = 0;
+    if (ntaps <= 16 && (1 << ts.sh) == cpt) {
+        for (int t = 0; t < ntaps; ++t)
+            if ((mask >> t) & 1u) { ts.seq |= (unsigned long long)t << (4 * ts.ntap); ++ts.ntap; }
+    } else { ts.ntap = -1; }                                 // no table: K-tile t is simply channels 64 t of the tap-major K axis
+    return ts;
+}
+__device__ __forceinline__ int tap_k0(const av_gemm_args& p, const TapSeq& ts, int t) {
+    if (ts.ntap < 0) return t * BK;
+    const int tap = (int)((ts.seq >> (4 * (t >> ts.sh))) & 15ull);
+    return tap * p.cCin + ((t & ((1 << ts.sh) - 1)) << 6);
+}
+
 // per tile row handled by this lane: pointer to the (ky = 0, kx = 0) tap pixel (+ the lane's swizzled 16-B chunk) and a bit mask of
 // the taps that fall inside the image (bit ky * Kw + kx for Kh * Kw <= 32; the valid ky range for longer 1-D filters).  A K-step then costs one 64-bit add and a select per row.
 struct ConvRows { const bf16_t* rowp[4]; unsigned valid[4]; };
@@ -105,12 +152,10 @@ __device__ __forceinline__ void conv_rows_init(ConvRows& cr, const bf16_t* __res
         cr.rowp[i] = base;
         cr.valid[i] = 0u;
         if (m < p.M) {
-            const int ox = m % p.cOw;
-            int q = m / p.cOw;
-            const int oy = q % p.cOh;
-            q /= p.cOh;
+            int q, oy, ox;
+            conv_decode(p, m, q, oy, ox);
             const int iy0 = oy * p.cSh - p.cPh, ix0 = ox * p.cSw - p.cPw;
-            cr.rowp[i] = base + (((long long)q * p.cH + iy0) * p.cW + ix0) * p.cCtot + p.cCoff + choff;
+            cr.rowp[i] = base + conv_pixel(p, q, iy0, ix0) * p.cCtot + p.cCoff + choff;
             unsigned v = 0u;
             if (p.cKh * p.cKw <= 32) {
                 for (int ky = 0; ky < p.cKh; ++ky)
@@ -132,7 +177,7 @@ __device__ __forceinline__ void stage_conv(const av_gemm_args& p, const ConvRows
     const int sub = lane >> 3, pch = lane & 7;
     const int tap = k0 / p.cCin, c0 = k0 - tap * p.cCin;
     const int ky = tap / p.cKw, kx = tap - ky * p.cKw;
-    const long long toff = ((long long)ky * p.cW + kx) * p.cCtot + c0;          // wave-uniform
+    const long long toff = ((long long)ky * p.cW + kx) * ((p.cPM & 1) ? p.cNF : 1) * p.cCtot + c0;          // wave-uniform
     const bf16_t* zl = (const bf16_t*)g_zero_line + ((pch ^ sub) << 3);
     const bool ranged = p.cKh * p.cKw > 32;
 #pragma unroll
@@ -320,15 +365,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    TapSeq ts;
+    ts.seq = 0ull; ts.ntap = -1; ts.sh = 0;
+    if constexpr (CONV) { if (p.cPM) ts = tap_seq(p, m0, BM); }
     auto stage = [&](int kt, char* buf) {
-        if constexpr (CONV) stage_conv(p, cr, kt * BK, buf, w, lane);
+        int k0 = kt * BK;
+        if constexpr (CONV) { k0 = tap_k0(p, ts, kt); stage_conv(p, cr, k0, buf, w, lane); }
         else if constexpr (AKM) stage_kmajor(A, p.lda, m0, p.M, kt * BK, Kz, buf, w, lane);
         else stage_rows<4>(A, p.lda, m0, p.M, kt * BK, buf, w, lane);
         if constexpr (BKM) stage_kmajor(B, p.ldb, n0, p.N, kt * BK, Kz, buf + TILE_A, w, lane);
-        else stage_rows<BNT / 32>(B, p.ldb, n0, p.N, kt * BK, buf + TILE_A, w, lane);
+        else stage_rows<BNT / 32>(B, p.ldb, n0, p.N, k0, buf + TILE_A, w, lane);
     };
 
-    const int nk = (Kz + BK - 1) / BK;                       // a ragged last K-step only with k-major operands (rows >= K are zero lines)
+    int nk = (Kz + BK - 1) / BK;                             // a ragged last K-step only with k-major operands (rows >= K are zero lines)
+    if constexpr (CONV) { if (ts.ntap >= 0) nk = ts.ntap << ts.sh; }
     KmOff ao[WM_T], bo[4];
     if constexpr (AKM) {
 #pragma unroll
@@ -877,12 +927,10 @@ __device__ __forceinline__ void conv_rows2_init(ConvRows2& cr, const bf16_t* __r
         cr.rowp[i] = base;
         cr.valid[i] = 0u;
         if (m < p.M) {
-            const int ox = m % p.cOw;
-            int q = m / p.cOw;
-            const int oy = q % p.cOh;
-            q /= p.cOh;
+            int q, oy, ox;
+            conv_decode(p, m, q, oy, ox);
             const int iy0 = oy * p.cSh - p.cPh, ix0 = ox * p.cSw - p.cPw;
-            cr.rowp[i] = base + (((long long)q * p.cH + iy0) * p.cW + ix0) * p.cCtot + p.cCoff + choff;
+            cr.rowp[i] = base + conv_pixel(p, q, iy0, ix0) * p.cCtot + p.cCoff + choff;
             unsigned v = 0u;
             for (int ky = 0; ky < p.cKh; ++ky)
                 for (int kx = 0; kx < p.cKw; ++kx)
@@ -895,7 +943,7 @@ __device__ __forceinline__ void stage_conv2(const av_gemm_args& p, const ConvRow
     const int sub = lane >> 3, pch = lane & 7;
     const int tap = k0 / p.cCin, c0 = k0 - tap * p.cCin;
     const int ky = tap / p.cKw, kx = tap - ky * p.cKw;
-    const long long toff = ((long long)ky * p.cW + kx) * p.cCtot + c0;          // wave-uniform
+    const long long toff = ((long long)ky * p.cW + kx) * ((p.cPM & 1) ? p.cNF : 1) * p.cCtot + c0;          // wave-uniform
     const bf16_t* zl = (const bf16_t*)g_zero_line + ((pch ^ sub) << 3);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -965,16 +1013,23 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    const int nh = 4 * nk;                                   // half-tiles in issue order: slot j = s & 3 : 0 = A0, 1 = B1, 2 = A1, 3 = B0
+    int nk = p.K / BK;
     ConvRows2 cr0, cr1;                                      // CONV: tap-0 pixel pointers + in-image tap masks of my rows of A0 / A1
-    if constexpr (CONV) { conv_rows2_init(cr0, A, p, m0, w, lane); conv_rows2_init(cr1, A, p, m0 + 128, w, lane); }
+    TapSeq ts;
+    ts.seq = 0ull; ts.ntap = -1; ts.sh = 0;
+    if constexpr (CONV) {
+        conv_rows2_init(cr0, A, p, m0, w, lane); conv_rows2_init(cr1, A, p, m0 + 128, w, lane);
+        if (p.cPM) { ts = tap_seq(p, m0, V4_BM); if (ts.ntap >= 0) nk = ts.ntap << ts.sh; }       // taps outside the image for this tile's position: skipped
+    }
+    const int nh = 4 * nk;                                   // half-tiles in issue order: slot j = s & 3 : 0 = A0, 1 = B1, 2 = A1, 3 = B0
     auto issue = [&](int t, int j) {                         // j is a compile-time constant at every call site
         char* slot = smem + (t & 1) * V4_KT + j * V4_HALF;
-        if (j == 0) { if constexpr (CONV) stage_conv2(p, cr0, t * BK, slot, w, lane); else stage_rows<2>(A, p.lda, m0, p.M, t * BK, slot, w, lane); }
-        else if (j == 2) { if constexpr (CONV) stage_conv2(p, cr1, t * BK, slot, w, lane); else stage_rows<2>(A, p.lda, m0 + 128, p.M, t * BK, slot, w, lane); }
-        else if (j == 3) stage_rows<2>(B, p.ldb, n0, p.N, t * BK, slot, w, lane);
-        else stage_rows<2>(B, p.ldb, n0 + 128, p.N, t * BK, slot, w, lane);
+        int k0 = t * BK;
+        if constexpr (CONV) k0 = tap_k0(p, ts, t);
+        if (j == 0) { if constexpr (CONV) stage_conv2(p, cr0, k0, slot, w, lane); else stage_rows<2>(A, p.lda, m0, p.M, k0, slot, w, lane); }
+        else if (j == 2) { if constexpr (CONV) stage_conv2(p, cr1, k0, slot, w, lane); else stage_rows<2>(A, p.lda, m0 + 128, p.M, k0, slot, w, lane); }
+        else if (j == 3) stage_rows<2>(B, p.ldb, n0, p.N, k0, slot, w, lane);
+        else stage_rows<2>(B, p.ldb, n0 + 128, p.N, k0, slot, w, lane);
     };
     // prologue: half-tiles 0..5 (K-tile 0 and A0, B1 of K-tile 1)
     issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
@@ -1149,6 +1204,7 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     if (!al16(p.A) || !al16(p.B) || p.M < 1 || p.N < 1) return -1;
     if (conv) {
         if (p.cCin % 64 || p.cCtot % 8 || p.cCoff % 8 || (p.cKh * p.cKw > 32 && (p.cKw != 1 || p.cKh > 65535))) return -1;
+        if (p.cPM && (p.cNF < 1 || p.cT != 1 || p.cKt != 1 || p.batch != 1 || p.cKh * p.cKw > 32 || p.M % (p.cOh * p.cOw * p.cNF))) return -1;     // position-major: plain 2-D convolutions, whole image blocks
     } else {
         if (p.lda % 8 || p.stats) return -1;
     }

@@ -147,13 +147,19 @@ __global__ void bn_prelu_maxpool_kernel(const T* __restrict__ x, const float* __
 }
 
 template <typename T>
-__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, long long N, int HW, int C) {
+__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, long long N, int HW, int C, int pos_major) {
     const long long tot = N * C;
+    const int FB = pos_major;                                                  // images per position-major block (0: frame-major)
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
         const long long img = e / C;
         float s = 0.f;
-        for (int p = 0; p < HW; ++p) s += to_f32<T>(x[(img * HW + p) * C + c]);
+        if (FB > 0) {
+            const long long blk = img / FB, fi = img - blk * FB;
+            for (int p = 0; p < HW; ++p) s += to_f32<T>(x[((blk * HW + p) * FB + fi) * C + c]);
+        } else {
+            for (int p = 0; p < HW; ++p) s += to_f32<T>(x[(img * HW + p) * C + c]);
+        }
         out[e] = s / (float)HW;
     }
 }
@@ -334,11 +340,11 @@ extern "C" int av_bn_prelu_maxpool(const void* x, const float* scale, const floa
     return AV_OK;
 }
 
-extern "C" int av_avgpool(const void* x, int dtype, float* out, long long N, int HW, int C, void* stream) {
-    AV_CHECK(x && out && HW > 0 && C > 0, "av_avgpool: bad args");
+extern "C" int av_avgpool(const void* x, int dtype, float* out, long long N, int HW, int C, int pos_major, void* stream) {
+    AV_CHECK(x && out && HW > 0 && C > 0 && pos_major >= 0 && (pos_major == 0 || N % pos_major == 0), "av_avgpool: bad args");
     if (N == 0) return AV_OK;
-    if (dtype == AV_F32) hipLaunchKernelGGL(avgpool_kernel<float>, dim3(ew_grid(N * C)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, N, HW, C);
-    else hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(ew_grid(N * C)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, N, HW, C);
+    if (dtype == AV_F32) hipLaunchKernelGGL(avgpool_kernel<float>, dim3(ew_grid(N * C)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, N, HW, C, pos_major);
+    else hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(ew_grid(N * C)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, N, HW, C, pos_major);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

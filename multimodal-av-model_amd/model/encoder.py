@@ -85,6 +85,12 @@ _TRUNK = ((64, 1), (128, 2), (256, 2), (512, 2))      # (planes, stride of the f
 
 FAST_C64 = os.environ.get("AVAMD_CONV_C64", "1") != "0"        # 0: layer1 through the implicit-GEMM kernel (A/B runs)
 FUSE_MID_ACT = os.environ.get("AVAMD_FUSE_MID_ACT", "1") != "0"  # 0: separate BN-apply + PReLU pass between conv1 and conv2 of layer1 (A/B runs)
+# ResNet layers 2-4 in POSITION-MAJOR pixel order (blocks of 256 frames, [block][y][x][frame of the block][C] instead of [frame][y][x][C], bf16 mode, frame count a
+# multiple of 256): every row tile of a convolution then
+# lies at one image position, and the filter taps that fall outside the (12x12 / 6x6 / 3x3) image for that position are skipped as whole
+# K-tiles instead of multiplying zero lines - 11 % / 21 % / 40 % of the implicit-GEMM work of layer2 / layer3 / layer4.  BatchNorm, PReLU and
+# the residual adds are per-pixel, so they do not see the order; the average pool reads it.  0: frame-major everywhere (A/B runs)
+POS_MAJOR = os.environ.get("AVAMD_CONV_POSMAJOR", "1") != "0"
 
 
 class BasicBlock(nn.Module):
@@ -214,9 +220,10 @@ class VisualEncoder(nn.Module):
         return (dtype == torch.bfloat16 and (k, st, pad, Cin, conv.out_channels) == (3, 1, 1, 64, 64) and W <= 31
                 and N * H * W < (1 << 24) and FAST_C64)
 
-    def _conv2d(self, x, N, H, W, Cin, conv: nn.Module, dtype, training: bool, in_act=None):
+    def _conv2d(self, x, N, H, W, Cin, conv: nn.Module, dtype, training: bool, in_act=None, pm: int = 0):
         """``in_act`` = (scale, shift, slope): x is the RAW output of the previous convolution and its BatchNorm-apply + PReLU is
-        applied while the input window is staged (layer1 kernel only: callers check ``_c64_ok``)."""
+        applied while the input window is staged (layer1 kernel only: callers check ``_c64_ok``).
+        ``pm``: bit 0 = x is in position-major pixel order, bit 1 = write the output position-major (av_gemm_args.cPM)."""
         k, st = conv.kernel_size[0], conv.stride[0]
         pad = conv.padding[0]
         Cout = conv.out_channels
@@ -235,7 +242,7 @@ class VisualEncoder(nn.Module):
         nblk = (M + 127) // 128
         stats = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device) if training else None
         geo = dict(cT=1, cH=H, cW=W, cCtot=Cin, cCin=Cin, cCoff=0, cKt=1, cKh=k, cKw=k, cSh=st, cSw=st, cPt=0, cPh=pad, cPw=pad,
-                   cOh=Ho, cOw=Wo)
+                   cOh=Ho, cOw=Wo, cNF=256 if pm else 0, cPM=pm)
         ops.gemm(x, self._w(conv, dtype), y, M=M, N=Cout, K=k * k * Cin, lda=0, ldb=k * k * Cin, ldc=Cout, a_mode=L.A_CONV2D,
                  conv=geo, stats=stats)
         return y, stats, nblk, M, Ho, Wo
@@ -285,9 +292,31 @@ class VisualEncoder(nn.Module):
         L.check(L.lib().av_bn_prelu_maxpool(ops.ptr(y), ops.ptr(sc), ops.ptr(sh), ops.ptr(self.frontend3D[2].weight.data), ops.ptr(h),
                                             ops.dt(h), N, Ho, Wo, 64, ops.stream()), "av_bn_prelu_maxpool")
         Hc, Wc, Cc = Hp, Wp, 64
+        # position-major order from layer2 on (bf16 fast path: input channels a multiple of 64, plain 3x3 / 1x1 filters)
+        FB = 256                                                # frames per position-major block = the row tile of the 8-phase kernel
+        use_pm = POS_MAJOR and dtype == torch.bfloat16 and N % FB == 0
+        pm_in = 0                                               # pixel order of h
         for li in range(1, 5):
             for blk in getattr(self.trunk, f"layer{li}"):
                 slope = blk.relu.weight.data
+                pm_out = 1 if (use_pm and li >= 2) else 0
+                pm1 = pm_in | (pm_out << 1)                     # conv1 / downsample: read h's order, write the layer's order
+                pm2 = pm_out * 3                                # conv2: both sides in the layer's order
+                if pm_out:
+                    c1, st1, nb1, M1, H1, W1 = self._conv2d(h, N, Hc, Wc, Cc, blk.conv1, dtype, training, pm=pm1)
+                    s1, b1 = self._bn(blk.bn1, st1, nb1, M1, training)
+                    a1 = self._act(c1, s1, b1, slope)
+                    c2, st2, nb2, M2, _, _ = self._conv2d(a1, N, H1, W1, blk.conv1.out_channels, blk.conv2, dtype, training, pm=pm2)
+                    s2, b2 = self._bn(blk.bn2, st2, nb2, M2, training)
+                    if blk.downsample is not None:
+                        cd, std, nbd, Md, _, _ = self._conv2d(h, N, Hc, Wc, Cc, blk.downsample[0], dtype, training, pm=pm1)
+                        sd, bd = self._bn(blk.downsample[1], std, nbd, Md, training)
+                        h = self._act(c2, s2, b2, slope, res=cd, rscale=sd, rshift=bd)
+                    else:
+                        h = self._act(c2, s2, b2, slope, res=h)
+                    Hc, Wc, Cc = H1, W1, blk.conv1.out_channels
+                    pm_in = 1
+                    continue
                 c1, st1, nb1, M1, H1, W1 = self._conv2d(h, N, Hc, Wc, Cc, blk.conv1, dtype, training)
                 s1, b1 = self._bn(blk.bn1, st1, nb1, M1, training)
                 if FUSE_MID_ACT and self._c64_ok(blk.conv2, dtype, N, H1, W1, blk.conv1.out_channels):
@@ -309,7 +338,7 @@ class VisualEncoder(nn.Module):
             torch._foreach_add_(self._nbt, 1)
             self._nbt = []
         out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
-        L.check(L.lib().av_avgpool(ops.ptr(h), ops.dt(h), ops.ptr(out), N, Hc * Wc, Cc, ops.stream()), "av_avgpool")
+        L.check(L.lib().av_avgpool(ops.ptr(h), ops.dt(h), ops.ptr(out), N, Hc * Wc, Cc, FB if pm_in else 0, ops.stream()), "av_avgpool")
         return out.view(B, T, Cc)
 
     def forward(self, x):

@@ -44,6 +44,38 @@ def test_visual_encoder(precision, tol, training):
         assert int(now["frontend3D.1.num_batches_tracked"]) == 1
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_visual_encoder_position_major_layers_equal_frame_major(training):
+    """ResNet layers 2-4 in blocked position-major pixel order (model/encoder.py: POS_MAJOR; av_gemm_args.cNF / cPM: rows of a tile share
+    their image position, out-of-image filter taps are skipped as whole K-tiles) against the frame-major path on the same input: 512 frames
+    (two blocks of 256), train-mode batch statistics and eval mode.  Skipped taps only drop exact zeros from the fp32 accumulations, so the
+    convolution outputs agree to rounding of the batch statistics (summed in another order)."""
+    _p("bf16")
+    init = pkg("utils.init"); enc = pkg("model.encoder")
+    sd = init.visual_state_dict()
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(4, 1, 128, 96, 96, generator=g).cuda()
+    outs, stats = [], []
+    for pm in (False, True):
+        enc.POS_MAJOR = pm
+        try:
+            ve = enc.VisualEncoder().cuda(); ve.load_state_dict(sd)
+            for p in ve.parameters():
+                p.requires_grad = False
+            ve.train(training)
+            outs.append(ve(x).float().cpu())
+            stats.append({k: v.float().cpu() for k, v in ve.state_dict().items() if "running" in k})
+        finally:
+            enc.POS_MAJOR = True
+    scale = float(outs[0].abs().max())
+    err = float((outs[0] - outs[1]).abs().max())
+    print("position-major vs frame-major: max |d| =", err, "of", scale)
+    assert outs[0].shape == (4, 128, 512) and err <= 2e-2 * scale
+    if training:
+        for k in stats[0]:
+            assert float((stats[0][k] - stats[1][k]).abs().max()) <= 1e-3 * max(1.0, float(stats[0][k].abs().max())), k
+
+
 @pytest.mark.parametrize("precision,tol,gtol", [("fp32", 1e-3, 2e-3), ("bf16", 6e-2, 0.1)])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_fusion_fwd_bwd(precision, tol, gtol, ragged):
