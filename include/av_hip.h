@@ -217,6 +217,9 @@ int av_permute_bt(const void* in, int idt, void* out, int odt, int B, int T, int
 int av_gather_rows(const void* src, int sdt, const long long* idx, void* out, int odt, long long n, int D, void* stream);
 int av_scatter_rows(const float* src, const long long* idx, float* out, long long n, int D, float alpha, int accumulate,
                     void* stream);
+/* contrastive.py:24-26 class order (anchors = mask 1, positives = 2, negatives = 0, anything else last), stable: order[] = what a stable
+ * argsort of the class rank gives; int64 in, int64 out, one launch */
+int av_class_order(const long long* mask, long long n, long long* order, void* stream);
 
 /* ---- lip-frame encoder glue (model/encoder.py:6-75): train-mode BatchNorm, PReLU, pooling; NHWC ------------ */
 /* bf16 fast path of the Conv3d(1->64,(5,7,7),(1,2,2),(2,3,3)) front-end (model/encoder.py:61): x [B*T][H][W] fp32,

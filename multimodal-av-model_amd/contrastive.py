@@ -61,17 +61,6 @@ def _term_fwd(A_t, P_t, n_rows, n_cols):
     return val, lse
 
 
-_RANK = {}
-
-
-def _class_rank(dev) -> torch.Tensor:
-    """mask value -> sort rank (1, 2, 0, 3), one constant tensor per device (building it per call is a blocking H2D copy)"""
-    t = _RANK.get(dev)
-    if t is None:
-        t = _RANK[dev] = torch.tensor([2, 0, 1, 3], device=dev)
-    return t
-
-
 class _ContrastFn(torch.autograd.Function):
     @staticmethod
     def forward(fctx, mid, flat_mask, pw, pb, counts):
@@ -81,8 +70,11 @@ class _ContrastFn(torch.autograd.Function):
         n1, n2, n0 = counts
         x = mid.contiguous().float().view(B * T, D)
         # class order 1 (anchors), 2 (positives), 0 (negatives), 3 (dropped): integer index plumbing only
-        key = _class_rank(dev)[flat_mask.clamp(0, 3)]
-        order = torch.argsort(key, stable=True)
+        fm = flat_mask.contiguous()
+        if fm.dtype != torch.long:
+            fm = fm.long()
+        order = torch.empty(B * T, dtype=torch.long, device=dev)
+        L.check(L.lib().av_class_order(ops.ptr(fm), B * T, ops.ptr(order), ops.stream()), "av_class_order")
         n = n1 + n2 + n0
         rows = torch.empty((n, D), dtype=dtype, device=dev)
         L.check(L.lib().av_gather_rows(ops.ptr(x), ops.dt(x), ops.ptr(order), ops.ptr(rows), ops.dt(rows), n, D, ops.stream()), "av_gather_rows")

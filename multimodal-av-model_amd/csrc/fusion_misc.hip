@@ -141,6 +141,42 @@ __global__ void gather_rows_kernel(const void* __restrict__ src, int sdt, const 
         st_any(out, e, odt, ld_any(src, idx[rrow] * D + k, sdt));
     }
 }
+// Stable class order of the contrastive loss (contrastive.py:24-26 of the reference: anchors = mask 1, positives = 2, negatives = 0, the
+// rest dropped): order[] = the indices of mask == 1 in ascending order, then those of 2, of 0, and of everything else - what a stable
+// argsort of the class rank returns, in ONE launch of one workgroup (the sort was ~10 launches of radix / merge passes for 12 736 keys).
+// Thread t owns the contiguous chunk [t * per, (t + 1) * per): per-class counts -> exclusive scan over the threads in LDS -> ordered writes.
+__global__ __launch_bounds__(1024) void class_order_kernel(const long long* __restrict__ mask, long long n, long long* __restrict__ order) {
+    __shared__ int cnt[4][1024];
+    __shared__ int tot[4];
+    const int t = threadIdx.x;
+    const long long per = (n + 1023) / 1024, lo = (long long)t * per, hi = lo + per < n ? lo + per : n;
+    int c[4] = {0, 0, 0, 0};
+    for (long long i = lo; i < hi; ++i) {
+        const long long m = mask[i];
+        const int k = m == 1 ? 0 : m == 2 ? 1 : m <= 0 ? 2 : 3;       // rank: 1, 2, 0 (values below 0 count as 0, above 3 as 3: the clamp of the counts)
+        ++c[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt[k][t] = c[k];
+    __syncthreads();
+    if (t < 4) {                                              // 4 serial scans of 1024 counters (one thread each): ~1 us, off any critical path
+        int run = 0;
+        for (int j = 0; j < 1024; ++j) { const int v = cnt[t][j]; cnt[t][j] = run; run += v; }
+        tot[t] = run;
+    }
+    __syncthreads();
+    long long base[4];
+    base[0] = cnt[0][t];
+    base[1] = (long long)tot[0] + cnt[1][t];
+    base[2] = (long long)tot[0] + tot[1] + cnt[2][t];
+    base[3] = (long long)tot[0] + tot[1] + tot[2] + cnt[3][t];
+    for (long long i = lo; i < hi; ++i) {
+        const long long m = mask[i];
+        const int k = m == 1 ? 0 : m == 2 ? 1 : m <= 0 ? 2 : 3;
+        order[k == 0 ? base[0]++ : k == 1 ? base[1]++ : k == 2 ? base[2]++ : base[3]++] = i;
+    }
+}
+
 __global__ void scatter_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx, float* __restrict__ out, long long n,
                                     int D, float alpha, int accumulate) {
     const long long tot = n * D;
@@ -219,6 +255,14 @@ extern "C" int av_scatter_rows(const float* src, const long long* idx, float* ou
     AV_CHECK(src && idx && out && D > 0, "av_scatter_rows: bad args");
     if (n == 0) return AV_OK;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(ew_grid(n * D)), dim3(256), 0, (hipStream_t)stream, src, idx, out, n, D, alpha, accumulate);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int av_class_order(const long long* mask, long long n, long long* order, void* stream) {
+    AV_CHECK(mask && order && n >= 0 && n < (1ll << 31), "av_class_order: bad args");
+    if (n == 0) return AV_OK;
+    hipLaunchKernelGGL(class_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, n, order);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

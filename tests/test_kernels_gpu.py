@@ -545,3 +545,17 @@ def test_fused_cross_attention_core_backward(B, T):
     ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], do, dq2, dkv2[:, :, 0], dkv2[:, :, 1], None, scale, o=o, lse=lse)
     torch.testing.assert_close(dq.float(), dq2.float(), rtol=3e-2, atol=3e-2)
     torch.testing.assert_close(dkv.float(), dkv2.float(), rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("n", [1, 7, 1023, 1025, 12736, 25472, 100003])
+def test_class_order_equals_stable_argsort_of_the_class_rank(n):
+    """av_class_order (contrastive.py:24-26: anchors 1, positives 2, negatives 0, the rest) == torch.argsort(rank, stable=True)."""
+    g = torch.Generator().manual_seed(n)
+    mask = torch.randint(0, 4, (n,), generator=g)
+    if n > 100:
+        mask[5] = -2; mask[17] = 9                               # out-of-range values: clamped like the counts (below 0 -> 0, above 3 -> 3)
+    m = mask.cuda()
+    order = torch.empty(n, dtype=torch.long, device="cuda")
+    L.check(L.lib().av_class_order(ops.ptr(m), n, ops.ptr(order), ops.stream()))
+    rank = torch.tensor([2, 0, 1, 3])[mask.clamp(0, 3)]
+    assert torch.equal(order.cpu(), torch.argsort(rank, stable=True))
