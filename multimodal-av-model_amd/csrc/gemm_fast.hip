@@ -1023,6 +1023,9 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     }
     const int nh = 4 * nk;                                   // half-tiles in issue order: slot j = s & 3 : 0 = A0, 1 = B1, 2 = A1, 3 = B0
     auto issue = [&](int t, int j) {                         // j is a compile-time constant at every call site
+#ifdef AV_ABL_NODMA
+        return;
+#endif
         char* slot = smem + (t & 1) * V4_KT + j * V4_HALF;
         int k0 = t * BK;
         if constexpr (CONV) k0 = tap_k0(p, ts, t);
@@ -1045,6 +1048,14 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
     bf16x8 fa[4][2], fb[2][2];
 
+// Diagnostic builds only (tools/gemm_ablate.py; never the product library): -DAV_ABL_NOMFMA keeps every LDS-DMA, fragment read, wait and
+// barrier of the main loop but issues no MFMA (the fragments are kept alive), -DAV_ABL_NODMA keeps the MFMAs and reads but stages nothing.
+// Timing the three builds on one shape says which resource paces the K-tile.
+#ifdef AV_ABL_NOMFMA
+#define V4_MFMA_OP(ACC, A, B) asm volatile("" :: "v"(A), "v"(B))
+#else
+#define V4_MFMA_OP(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, ACC, 0, 0, 0)
+#endif
 #define V4_READ_A(SLOT, NMT)                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < (NMT)) {                                                 \
         fa[i][0] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + a_row + i * 2048 + ch0);                               \
@@ -1061,7 +1072,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < ((QA) ? nmt1 : nmt0))                                \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-                acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[QA][QB][i][j], 0, 0, 0); \
+                V4_MFMA_OP(acc[QA][QB][i][j], fa[i][ks], fb[j][ks]);                                               \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                  \
@@ -1092,6 +1103,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #undef V4_READ_A
 #undef V4_READ_B
 #undef V4_MMA
+#undef V4_MFMA_OP
     if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the entry barrier of wavefronts 4-7
     AV_STAMP(2);
 
