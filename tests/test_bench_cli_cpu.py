@@ -44,3 +44,21 @@ def test_flop_accounting_matches_survey_numbers():
     conv = sum(2.0 * k * ci * c * L for k, ci, c, L in zip(cfg["conv_kernel"], (1,) + tuple(cfg["conv_dim"][:-1]), cfg["conv_dim"],
                                                             (12799, 6399, 3199, 1599, 799, 399, 199))) / 1e9
     assert abs((two + conv) - 682.0) < 2.0
+
+
+def test_flop_accounting_counts_executed_layers():
+    """The LayerDrop draws are on the host, so bench.py prices the layers actually executed (forward / backward without / with weight
+    gradients, summed over the passes), not an expectation: all layers executed = the plain two-pass figure; a dropped layer removes exactly
+    its own forward and backward products."""
+    b = _load_bench()
+    cfg = pkg("utils.init").W2V2_LARGE
+    full = b.flops_per_utt(cfg, 64000, 100, 2)
+    assert b.flops_per_utt(cfg, 64000, 100, 2, (48, 28, 8)) == full
+    H, I, T = cfg["hidden_size"], cfg["intermediate_size"], 199
+    lin = (8.0 * H * H + 4.0 * H * I) * T
+    att = 4.0 * T * T * H
+    # one frozen layer (no backward) and one trainable layer (dX + dW) dropped in one pass each
+    got = b.flops_per_utt(cfg, 64000, 100, 2, (46, 28, 7))
+    assert abs((full - got) - ((lin + att) + (lin + att) + (2 * lin + 2 * att))) < 1.0
+    # per-step averages need not be integers (LayerDrop over 30 timed steps)
+    assert b.flops_per_utt(cfg, 64000, 100, 2, (43.0, 25.13, 7.13)) < full
