@@ -93,12 +93,9 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(uint2* __restrict__ 
     if (q < Tq) {
         const unsigned long long base = ((unsigned long long)bh * Tq + q) * ((Tk + 3) & ~3);
         const int nt = (Tk + 15) >> 4;
+        const unsigned thr = (unsigned)__builtin_ceilf(drop_p * 65536.0f);     // u = k / 65536 >= p  <=>  k >= ceil(65536 p)
         for (int t = 0; t < nt; ++t) {
-            float u[4];
-            drop_uniform4(seed, stream_id, base + (16 * t + 4 * g), u);
-            unsigned nib = 0u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) nib |= (u[e] >= drop_p ? 1u : 0u) << e;
+            const unsigned nib = drop_keep4(seed, stream_id, base + (16 * t + 4 * g), thr);
             if (t < 8) lo |= nib << (4 * t); else hi |= nib << (4 * (t - 8));
         }
     }

@@ -72,34 +72,36 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // odd polynomial z P(z^2) of degree 17 fitted on [0, 3] (|err| <= 2.8e-5, GELU abs err <= 5.8e-5, GELU' <= 1.4e-5: far below bf16
 // resolution), 1 beyond - 9 FMAs and no transcendental (the Abramowitz-Stegun form cost an exp and a reciprocal on top of 5 FMAs)
 __device__ __forceinline__ float erf_abs_poly(float z) {
+    // explicit fused multiply-adds: the library is built with -ffp-contract=off (bit-exact BatchNorm / fp32-parity paths), under which
+    // `p * z2 + c` is a multiply AND an add - twice the vector slots of this Horner chain while a GEMM's matrix pipes wait for its epilogue
     const float z2 = z * z;
     float p = 4.0719861260640755e-08f;
-    p = p * z2 + -1.9457509097264847e-06f;
-    p = p * z2 + 4.110950976610184e-05f;
-    p = p * z2 + -0.0005118074477650225f;
-    p = p * z2 + 0.004241328686475754f;
-    p = p * z2 + -0.025126988068223f;
-    p = p * z2 + 0.11113087832927704f;
-    p = p * z2 + -0.37536558508872986f;
-    p = p * z2 + 1.1282844543457031f;
+    p = __builtin_fmaf(p, z2, -1.9457509097264847e-06f);
+    p = __builtin_fmaf(p, z2, 4.110950976610184e-05f);
+    p = __builtin_fmaf(p, z2, -0.0005118074477650225f);
+    p = __builtin_fmaf(p, z2, 0.004241328686475754f);
+    p = __builtin_fmaf(p, z2, -0.025126988068223f);
+    p = __builtin_fmaf(p, z2, 0.11113087832927704f);
+    p = __builtin_fmaf(p, z2, -0.37536558508872986f);
+    p = __builtin_fmaf(p, z2, 1.1282844543457031f);
     return z >= 3.0f ? 1.0f : p * z;
 }
 __device__ __forceinline__ float gelu_fast(float x) {
     const float e = erf_abs_poly(fabsf(x) * 0.70710678118654752440f);
     const float t = 0.5f * x;
-    return t + fabsf(t) * e;                               // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
+    return __builtin_fmaf(fabsf(t), e, t);                 // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
 }
 __device__ __forceinline__ float gelu_grad_fast(float x) {
     const float e = erf_abs_poly(fabsf(x) * 0.70710678118654752440f);
-    const float cdf = 0.5f + (x < 0.f ? -0.5f : 0.5f) * e;
-    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    const float cdf = __builtin_fmaf(x < 0.f ? -0.5f : 0.5f, e, 0.5f);
+    return __builtin_fmaf(x * 0.39894228040143267794f, __expf(-0.5f * x * x), cdf);
 }
 // gelu(x) and gelu'(x) from ONE erf evaluation (AV_ACT_GELU_GF)
 __device__ __forceinline__ void gelu_both_fast(float x, float& gl, float& gp) {
     const float e = erf_abs_poly(fabsf(x) * 0.70710678118654752440f);
     const float t = 0.5f * x;
-    gl = t + fabsf(t) * e;
-    gp = 0.5f + (x < 0.f ? -0.5f : 0.5f) * e + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    gl = __builtin_fmaf(fabsf(t), e, t);
+    gp = __builtin_fmaf(x * 0.39894228040143267794f, __expf(-0.5f * x * x), __builtin_fmaf(x < 0.f ? -0.5f : 0.5f, e, 0.5f));
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -145,12 +147,24 @@ __device__ __forceinline__ float drop_mult(unsigned long long seed, unsigned str
 __device__ __noinline__ float drop_mult_call(unsigned long long seed, unsigned stream, unsigned long long idx, float p, float inv_keep) {
     return drop_mult(seed, stream, idx, p, inv_keep);
 }
-// 4 consecutive elements starting at a multiple of 4 (one generator call)
+// keep bits (bit e = element idx4 + e is kept) of an aligned group of four under drop probability p (thr = ceil(65536 p))
+__device__ __forceinline__ unsigned drop_keep4(unsigned long long seed, unsigned stream, unsigned long long idx4, unsigned thr) {
+    const unsigned long long blk = idx4 >> 2;
+    const unsigned c1 = (unsigned)(blk >> 32);
+    const unsigned x = (unsigned)blk ^ drop_key(seed, stream) ^ c1 ^ __builtin_rotateleft32(c1, 11) ^ __builtin_rotateleft32(c1, 23);
+    const unsigned o0 = mix32(x), o1 = mix32(x + 0x9E3779B9u);
+    return ((o0 & 0xFFFFu) >= thr ? 1u : 0u) | ((o0 >> 16) >= thr ? 2u : 0u) | ((o1 & 0xFFFFu) >= thr ? 4u : 0u) | ((o1 >> 16) >= thr ? 8u : 0u);
+}
+// 4 consecutive elements starting at a multiple of 4 (one generator call).  The keep test runs on the 16-bit integers: u = k / 65536 >= p
+// <=> k >= ceil(65536 p) (both sides exact in fp32), which spares the int -> float conversion and the scaling of every element.
 __device__ __forceinline__ void drop_mult4(unsigned long long seed, unsigned stream, unsigned long long idx4, float p, float inv_keep, float (&m)[4]) {
-    float u[4];
-    drop_uniform4(seed, stream, idx4, u);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = u[i] >= p ? inv_keep : 0.f;
+    const unsigned long long blk = idx4 >> 2;
+    const unsigned c1 = (unsigned)(blk >> 32);
+    const unsigned x = (unsigned)blk ^ drop_key(seed, stream) ^ c1 ^ __builtin_rotateleft32(c1, 11) ^ __builtin_rotateleft32(c1, 23);
+    const unsigned o0 = mix32(x), o1 = mix32(x + 0x9E3779B9u);
+    const unsigned thr = (unsigned)__builtin_ceilf(p * 65536.0f);
+    m[0] = (o0 & 0xFFFFu) >= thr ? inv_keep : 0.f; m[1] = (o0 >> 16) >= thr ? inv_keep : 0.f;
+    m[2] = (o1 & 0xFFFFu) >= thr ? inv_keep : 0.f; m[3] = (o1 >> 16) >= thr ? inv_keep : 0.f;
 }
 
 static inline int av_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
