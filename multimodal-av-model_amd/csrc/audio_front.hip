@@ -133,7 +133,11 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_c512_kernel(const float* __
             const float xj = xv[j];
             const f32x4 w0 = *(const f32x4*)(sw + (j * 64 + lane) * 8), w1 = *(const f32x4*)(sw + (j * 64 + lane) * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] += w0[e] * xj; a[4 + e] += w1[e] * xj; }
+            for (int e = 0; e < 4; e += 2) {           // packed fp32 (two channels per vector slot), same multiply-then-add rounding per channel
+                const av_f32x2 xx = pk_splat(xj);
+                const av_f32x2 t0 = av_f32x2{a[e], a[e + 1]} + av_f32x2{w0[e], w0[e + 1]} * xx, t1 = av_f32x2{a[4 + e], a[5 + e]} + av_f32x2{w1[e], w1[e + 1]} * xx;
+                a[e] = t0.x; a[e + 1] = t0.y; a[4 + e] = t1.x; a[5 + e] = t1.y;
+            }
         }
         float s = 0.f;
 #pragma unroll
@@ -147,7 +151,11 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_c512_kernel(const float* __
         if (sizeof(TO) == 2) {
             bf16x8 ov;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)gelu_fast((a[e] - mean) * rstd * gl[e] + btl[e]);
+            for (int e = 0; e < 8; e += 2) {
+                const av_f32x2 t = (av_f32x2{a[e], a[e + 1]} - pk_splat(mean)) * pk_splat(rstd) * av_f32x2{gl[e], gl[e + 1]} + av_f32x2{btl[e], btl[e + 1]};
+                const av_f32x2 g = gelu_fast2(t);
+                ov[e] = (bf16_t)g.x; ov[e + 1] = (bf16_t)g.y;
+            }
             *(bf16x8*)o = ov;
         } else {
 #pragma unroll

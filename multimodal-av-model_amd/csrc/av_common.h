@@ -103,6 +103,48 @@ __device__ __forceinline__ void gelu_both_fast(float x, float& gl, float& gp) {
     gl = __builtin_fmaf(fabsf(t), e, t);
     gp = __builtin_fmaf(x * 0.39894228040143267794f, __expf(-0.5f * x * x), __builtin_fmaf(x < 0.f ? -0.5f : 0.5f, e, 0.5f));
 }
+// Packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32: two elements per vector slot), the same operation sequence per element as the scalar
+// functions above, so results are bit-identical to them.
+typedef float av_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ av_f32x2 pk_fma(av_f32x2 a, av_f32x2 b, av_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ av_f32x2 pk_splat(float c) { return av_f32x2{c, c}; }
+__device__ __forceinline__ av_f32x2 erf_abs_poly2(av_f32x2 z) {
+    const av_f32x2 z2 = z * z;
+    av_f32x2 p = pk_splat(4.0719861260640755e-08f);
+    p = pk_fma(p, z2, pk_splat(-1.9457509097264847e-06f));
+    p = pk_fma(p, z2, pk_splat(4.110950976610184e-05f));
+    p = pk_fma(p, z2, pk_splat(-0.0005118074477650225f));
+    p = pk_fma(p, z2, pk_splat(0.004241328686475754f));
+    p = pk_fma(p, z2, pk_splat(-0.025126988068223f));
+    p = pk_fma(p, z2, pk_splat(0.11113087832927704f));
+    p = pk_fma(p, z2, pk_splat(-0.37536558508872986f));
+    p = pk_fma(p, z2, pk_splat(1.1282844543457031f));
+    av_f32x2 e = p * z;
+    e.x = z.x >= 3.0f ? 1.0f : e.x;
+    e.y = z.y >= 3.0f ? 1.0f : e.y;
+    return e;
+}
+__device__ __forceinline__ av_f32x2 pk_abs(av_f32x2 x) { return av_f32x2{fabsf(x.x), fabsf(x.y)}; }
+__device__ __forceinline__ av_f32x2 gelu_fast2(av_f32x2 x) {
+    const av_f32x2 e = erf_abs_poly2(pk_abs(x) * pk_splat(0.70710678118654752440f));
+    const av_f32x2 t = pk_splat(0.5f) * x;
+    return pk_fma(pk_abs(t), e, t);
+}
+__device__ __forceinline__ av_f32x2 gelu_grad_fast2(av_f32x2 x) {
+    const av_f32x2 e = erf_abs_poly2(pk_abs(x) * pk_splat(0.70710678118654752440f));
+    const av_f32x2 sg = av_f32x2{x.x < 0.f ? -0.5f : 0.5f, x.y < 0.f ? -0.5f : 0.5f};
+    const av_f32x2 cdf = pk_fma(sg, e, pk_splat(0.5f));
+    const av_f32x2 h = pk_splat(-0.5f) * x * x;
+    return pk_fma(x * pk_splat(0.39894228040143267794f), av_f32x2{__expf(h.x), __expf(h.y)}, cdf);
+}
+__device__ __forceinline__ void gelu_both_fast2(av_f32x2 x, av_f32x2& gl, av_f32x2& gp) {
+    const av_f32x2 e = erf_abs_poly2(pk_abs(x) * pk_splat(0.70710678118654752440f));
+    const av_f32x2 t = pk_splat(0.5f) * x;
+    gl = pk_fma(pk_abs(t), e, t);
+    const av_f32x2 sg = av_f32x2{x.x < 0.f ? -0.5f : 0.5f, x.y < 0.f ? -0.5f : 0.5f};
+    const av_f32x2 h = pk_splat(-0.5f) * x * x;
+    gp = pk_fma(x * pk_splat(0.39894228040143267794f), av_f32x2{__expf(h.x), __expf(h.y)}, pk_fma(sg, e, pk_splat(0.5f)));
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---- counter-based RNG for dropout: the mask of element `idx` of stream `stream` under `seed` is a pure function of (seed, stream, idx),

@@ -216,10 +216,12 @@ __device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const Fast
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float gl, gp;
-            gelu_both_fast(v[e], gl, gp);
-            v[e] = gl * m[e]; gf[e] = gp * m[e];
+        for (int e = 0; e < 8; e += 2) {
+            av_f32x2 gl, gp;
+            const av_f32x2 mm = av_f32x2{m[e], m[e + 1]};
+            gelu_both_fast2(av_f32x2{v[e], v[e + 1]}, gl, gp);
+            gl = gl * mm; gp = gp * mm;
+            v[e] = gl.x; v[e + 1] = gl.y; gf[e] = gp.x; gf[e + 1] = gp.y;
         }
         if (p.C2) {
             if (full && fl.c_vec && p.out_dtype == AV_BF16) {
@@ -251,7 +253,7 @@ __device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const Fast
     }
     if (p.act == AV_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        for (int e = 0; e < 8; e += 2) { const av_f32x2 g = gelu_fast2(av_f32x2{v[e], v[e + 1]}); v[e] = g.x; v[e + 1] = g.y; }
     } else if (p.act == AV_ACT_MUL_AUX) {
         if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
             const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
@@ -265,7 +267,7 @@ __device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const Fast
         if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
             const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u[e]);
+            for (int e = 0; e < 8; e += 2) { const av_f32x2 g = gelu_grad_fast2(av_f32x2{(float)u[e], (float)u[e + 1]}); v[e] *= g.x; v[e + 1] *= g.y; }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_fast(ld_any(p.aux, off + e, p.aux_dtype));
@@ -277,10 +279,10 @@ __device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const Fast
             float m4[4];
             drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= m4[e];
+            for (int e = 0; e < 4; e += 2) { const av_f32x2 t = av_f32x2{v[e], v[e + 1]} * av_f32x2{m4[e], m4[e + 1]}; v[e] = t.x; v[e + 1] = t.y; }
             drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off + 4, p.drop_p, ik, m4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 + e] *= m4[e];
+            for (int e = 0; e < 4; e += 2) { const av_f32x2 t = av_f32x2{v[4 + e], v[5 + e]} * av_f32x2{m4[e], m4[e + 1]}; v[4 + e] = t.x; v[5 + e] = t.y; }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
@@ -291,7 +293,10 @@ __device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const Fast
         if (full && fl.r_vec) {
             const f32x4 r0 = *(const f32x4*)(R + roff), r1 = *(const f32x4*)(R + roff + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            for (int e = 0; e < 4; e += 2) {
+                const av_f32x2 a = av_f32x2{v[e], v[e + 1]} + av_f32x2{r0[e], r0[e + 1]}, b = av_f32x2{v[4 + e], v[5 + e]} + av_f32x2{r1[e], r1[e + 1]};
+                v[e] = a.x; v[e + 1] = a.y; v[4 + e] = b.x; v[5 + e] = b.y;
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += R[roff + e];
@@ -527,10 +532,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float gl, gp;
-                gelu_both_fast(v[e], gl, gp);
-                v[e] = gl * m[e]; gf[e] = gp * m[e];
+            for (int e = 0; e < 8; e += 2) {
+                av_f32x2 gl, gp;
+                const av_f32x2 mm = av_f32x2{m[e], m[e + 1]};
+                gelu_both_fast2(av_f32x2{v[e], v[e + 1]}, gl, gp);
+                gl = gl * mm; gp = gp * mm;
+                v[e] = gl.x; v[e + 1] = gl.y; gf[e] = gp.x; gf[e + 1] = gp.y;
             }
             if (p.C2) {
                 if (full && fl.c_vec && p.out_dtype == AV_BF16) {
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
         }
         if (p.act == AV_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+            for (int e = 0; e < 8; e += 2) { const av_f32x2 g = gelu_fast2(av_f32x2{v[e], v[e + 1]}); v[e] = g.x; v[e + 1] = g.y; }
         } else if (p.act == AV_ACT_MUL_AUX) {
             if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
                 const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
             if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
                 const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)u[e]);
+                for (int e = 0; e < 8; e += 2) { const av_f32x2 g = gelu_grad_fast2(av_f32x2{(float)u[e], (float)u[e + 1]}); v[e] *= g.x; v[e + 1] *= g.y; }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= gelu_grad_fast(ld_any(p.aux, off + e, p.aux_dtype));

@@ -8,6 +8,7 @@ for val in 1 0 1 0; do
 import json, sys
 l = [x for x in open(f"gpurun_out/ab/{sys.argv[1]}_{sys.argv[2]}.log") if x.startswith("{")][-1]
 d = json.loads(l)
-print(sys.argv[1], "=", sys.argv[2], d["value"], "utt/s", d["ms_per_step"], "ms; roofline", d["roofline"]["achieved"], "TF/s", d["roofline"]["avg_launch_us"], "us", flush=True)
+r = d.get("roofline") or {}
+print(sys.argv[1], "=", sys.argv[2], d["value"], "utt/s", d["ms_per_step"], "ms; roofline", r.get("achieved"), "TF/s", r.get("avg_launch_us"), "us", flush=True)
 PY
 done
