@@ -199,7 +199,7 @@ int av_lstm_bwd_step(const void* dout, int dout_dtype, long long do_bs, long lon
  * are separated by an arrival counter (agent-coherent stores / loads, bounded spins: counters[2] is set on timeout).  W_hh slices
  * stay in registers for the whole sequence.  counters: AV_LSTM_COUNTER_INTS ints of device workspace (zeroed by the call).
  * Same buffers as the step kernels; results agree with them to fp32 rounding of the K-quarter partial sums. */
-#define AV_LSTM_COUNTER_INTS 512
+#define AV_LSTM_COUNTER_INTS 1024
 int av_lstm_fwd_layer(const float* gx, const void* whh, void* hseq, float* cseq, void* gates, void* out_bt, int* counters,
                       int T, int B, int H, void* stream);
 int av_lstm_bwd_layer(const void* dout, int dout_dtype, long long do_bs, long long do_ts, void* dgates, const void* whhT,

@@ -14,7 +14,7 @@ AV_F32, AV_BF16 = 0, 1
 A_ROWMAJOR, A_TRANS, A_CONV2D, A_CONV3D1 = 0, 1, 2, 3
 B_NK, B_KN = 0, 1
 ACT_NONE, ACT_GELU, ACT_MUL_GELU_GRAD, ACT_GELU_GF, ACT_MUL_AUX = 0, 1, 2, 3, 4
-LSTM_COUNTER_INTS = 512          # AV_LSTM_COUNTER_INTS: device workspace of av_lstm_*_layer
+LSTM_COUNTER_INTS = 1024         # AV_LSTM_COUNTER_INTS: device workspace of av_lstm_*_layer
 
 vp, ll, i32, f32 = C.c_void_p, C.c_longlong, C.c_int, C.c_float
 

@@ -368,8 +368,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
 // 64 KiB instead of 256 KiB) and 256 CUs pull instead of 64.  Same arithmetic order inside a K quarter; the cross-quarter sum is
 // ((q0 + q1) + q2) + q3 in fp32 (the 64-row kernel accumulates the same products in one chain: results agree to fp32 rounding).
 constexpr int CNT_STRIDE = 32;               // ints between counters
+constexpr int MAXRG = 8;                     // row groups per direction at most (two workgroups per CU on 256 CUs)
 constexpr int PSZ = 320;                     // floats of one padded 16 x 16 partial tile
-__device__ __forceinline__ int* group_counter(int* counters, int d, int z) { return counters + CNT_STRIDE * (1 + d * 4 + z); }
+__device__ __forceinline__ int* group_counter(int* counters, int d, int z) { return counters + CNT_STRIDE * (1 + d * MAXRG + z); }
 __device__ __forceinline__ int pidx(int row, int unit) { return (row >> 2) * 80 + (row & 3) * 16 + unit; }   // conflict-free for the C layout
 
 __global__ __launch_bounds__(256, 2) void lstm_fwd_split(const PF p) {
@@ -579,7 +580,10 @@ static int lstm_row_groups(int B) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     }
     const int ntile = (B + 15) / 16;
-    int nrg = ntile < 4 ? ntile : 4;
+    // up to 8 row groups = 512 workgroups, two per CU (forward 36 KB, backward 71 KB of LDS each): at B = 128 (both speakers in one call) every
+    // workgroup then has ONE 16-row tile per step instead of two in sequence.  AVAMD_LSTM_NRG caps it (4 = the round-2 geometry).
+    static const int cap = [] { const char* e = getenv("AVAMD_LSTM_NRG"); const int v = e ? atoi(e) : MAXRG; return v < 1 ? 1 : (v > MAXRG ? MAXRG : v); }();
+    int nrg = ntile < cap ? ntile : cap;
     while (nrg > 1 && 2 * NJT * nrg > 2 * ncu) --nrg;
     return 2 * NJT * nrg <= 2 * ncu ? nrg : 0;
 }
@@ -598,7 +602,7 @@ static int lstm_prepare(void) {
     return AV_OK;
 }
 
-// counters: AV_LSTM_COUNTER_INTS (512) ints of workspace (zeroed here); returns after enqueueing; the timeout flag counters[2] can be read later
+// counters: AV_LSTM_COUNTER_INTS (1024) ints of workspace (zeroed here); returns after enqueueing; the timeout flag counters[2] can be read later
 extern "C" int av_lstm_fwd_layer(const float* gx, const void* whh, void* hseq, float* cseq, void* gates, void* out_bt, int* counters,
                                  int T, int B, int Hh, void* stream) {
     AV_CHECK(gx && whh && hseq && cseq && counters, "av_lstm_fwd_layer: null pointer");
