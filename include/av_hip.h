@@ -114,6 +114,9 @@ int av_layernorm_bwd_drop(const void* x, int xdt, const void* dy, int dydt, cons
 /* F.log_softmax(dim=-1) (model/decoder.py:25) and its backward: dx = dy - exp(y) * sum(dy) */
 int av_log_softmax_fwd(const void* x, int xdt, float* y, long long rows, int cols, void* stream);
 int av_log_softmax_bwd(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, void* stream);
+/* the same with a row stride ldx >= cols for dx; columns [cols, ldx) are written as zeros, so that dx can feed a GEMM whose K is padded to a
+ * multiple of 64 (the CTC head's dX product: vocabulary 800 -> 832) */
+int av_log_softmax_bwd_ld(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, int ldx, void* stream);
 /* column sums of a [rows][cols] matrix (bias gradients): out[cols] (+)= sum_rows x */
 int av_colsum(const void* x, int xdt, float* out, long long rows, int cols, long long ld, int accumulate,
               void* stream);

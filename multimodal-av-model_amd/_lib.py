@@ -48,6 +48,7 @@ SIGNATURES = {
     "av_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp, vp],
     "av_log_softmax_fwd": [vp, i32, vp, ll, i32, vp],
     "av_log_softmax_bwd": [vp, vp, vp, i32, ll, i32, vp],
+    "av_log_softmax_bwd_ld": [vp, vp, vp, i32, ll, i32, i32, vp],
     "av_colsum": [vp, i32, vp, ll, i32, ll, i32, vp],
     "av_cast": [vp, i32, vp, i32, ll, vp],
     "av_cast_dropout": [vp, i32, vp, i32, ll, f32, C.c_ulonglong, C.c_uint, vp],

@@ -133,10 +133,12 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_c512_kernel(const float* __
             const float xj = xv[j];
             const f32x4 w0 = *(const f32x4*)(sw + (j * 64 + lane) * 8), w1 = *(const f32x4*)(sw + (j * 64 + lane) * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; e += 2) {           // packed fp32 (two channels per vector slot), same multiply-then-add rounding per channel
-                const av_f32x2 xx = pk_splat(xj);
-                const av_f32x2 t0 = av_f32x2{a[e], a[e + 1]} + av_f32x2{w0[e], w0[e + 1]} * xx, t1 = av_f32x2{a[4 + e], a[5 + e]} + av_f32x2{w1[e], w1[e + 1]} * xx;
-                a[e] = t0.x; a[e + 1] = t0.y; a[4 + e] = t1.x; a[5 + e] = t1.y;
+            for (int e = 0; e < 4; ++e) {
+                // the kernel is bound by vector issue (45 instructions per output element at 1.8 TB/s of stores).  bf16 output: fused
+                // multiply-adds (the library is built with -ffp-contract=off; packed fp32 issues at half rate and bought nothing);
+                // fp32 output (parity mode): multiply then add, as the reference's convolution rounds
+                if constexpr (sizeof(TO) == 2) { a[e] = __builtin_fmaf(w0[e], xj, a[e]); a[4 + e] = __builtin_fmaf(w1[e], xj, a[4 + e]); }
+                else { a[e] += w0[e] * xj; a[4 + e] += w1[e] * xj; }
             }
         }
         float s = 0.f;
@@ -145,17 +147,13 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_c512_kernel(const float* __
         const float mean = dpp_wave_sum(s) / C;
         float q = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = a[e] - mean; q += d * d; }
+        for (int e = 0; e < 8; ++e) { const float d = a[e] - mean; if constexpr (sizeof(TO) == 2) q = __builtin_fmaf(d, d, q); else q += d * d; }
         const float rstd = rsqrtf(dpp_wave_sum(q) / C + eps);
         TO* o = out + ((long long)b * L_out + f) * C + lane * 8;
         if (sizeof(TO) == 2) {
             bf16x8 ov;
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const av_f32x2 t = (av_f32x2{a[e], a[e + 1]} - pk_splat(mean)) * pk_splat(rstd) * av_f32x2{gl[e], gl[e + 1]} + av_f32x2{btl[e], btl[e + 1]};
-                const av_f32x2 g = gelu_fast2(t);
-                ov[e] = (bf16_t)g.x; ov[e + 1] = (bf16_t)g.y;
-            }
+            for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)gelu_fast(__builtin_fmaf(a[e] - mean, rstd * gl[e], btl[e]));
             *(bf16x8*)o = ov;
         } else {
 #pragma unroll

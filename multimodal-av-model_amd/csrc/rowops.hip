@@ -280,11 +280,11 @@ __global__ __launch_bounds__(256) void lsm_fwd_kernel(const void* __restrict__ x
 }
 
 __global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, void* __restrict__ dx,
-                                                      int dxdt, long long rows, int cols) {
+                                                      int dxdt, long long rows, int cols, int ldx) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const long long base = row * cols;
+    const long long base = row * cols, obase = row * ldx;
     float d[MAXIT];
     float s = 0.f;
 #pragma unroll
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int c = lane + 64 * it;
-        if (c < cols) st_any(dx, base + c, dxdt, d[it] - expf(y[base + c]) * s);
+        if (c < cols) st_any(dx, obase + c, dxdt, d[it] - expf(y[base + c]) * s);
+        else if (c < ldx) st_any(dx, obase + c, dxdt, 0.f);          // padding columns of a K-padded GEMM operand: exact zeros
     }
 }
 
@@ -556,13 +557,17 @@ extern "C" int av_log_softmax_fwd(const void* x, int xdt, float* y, long long ro
     return AV_OK;
 }
 
-extern "C" int av_log_softmax_bwd(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, void* stream) {
+extern "C" int av_log_softmax_bwd_ld(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, int ldx, void* stream) {
     AV_CHECK(y && dy && dx, "av_log_softmax_bwd: null pointer");
     AV_CHECK(cols > 0 && cols <= 64 * MAXIT, "av_log_softmax_bwd: cols=%d out of range", cols);
+    AV_CHECK(ldx >= cols && ldx <= 64 * MAXIT, "av_log_softmax_bwd: ldx=%d must lie in [cols=%d, %d]", ldx, cols, 64 * MAXIT);
     if (rows == 0) return AV_OK;
-    hipLaunchKernelGGL(lsm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, dxdt, rows, cols);
+    hipLaunchKernelGGL(lsm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, dxdt, rows, cols, ldx);
     AV_LAUNCH_CHECK();
     return AV_OK;
+}
+extern "C" int av_log_softmax_bwd(const float* y, const float* dy, void* dx, int dxdt, long long rows, int cols, void* stream) {
+    return av_log_softmax_bwd_ld(y, dy, dx, dxdt, rows, cols, cols, stream);
 }
 
 extern "C" int av_colsum(const void* x, int xdt, float* out, long long rows, int cols, long long ld, int accumulate, void* stream) {

@@ -335,21 +335,27 @@ def log_softmax_fwd(x: Tensor) -> Tensor:
     return y
 
 
-def log_softmax_bwd(y: Tensor, dy: Tensor, out_dtype: torch.dtype) -> Tensor:
+def log_softmax_bwd(y: Tensor, dy: Tensor, out_dtype: torch.dtype, pad_to: int = 0) -> Tensor:
+    """dx = dy - exp(y) * sum(dy).  ``pad_to`` > 0: the rows of dx are padded with zero columns to a multiple of it (returned tensor
+    [..., ceil(cols / pad_to) * pad_to]: a K-padded operand for the dX product of the layer below)."""
     cols = y.shape[-1]
-    dx = torch.empty(y.shape, dtype=out_dtype, device=y.device)
-    L.check(L.lib().av_log_softmax_bwd(ptr(y), ptr(dy), ptr(dx), dt(dx), y.numel() // cols, cols, stream()), "av_log_softmax_bwd")
+    ldx = (cols + pad_to - 1) // pad_to * pad_to if pad_to > 0 else cols
+    dx = torch.empty(y.shape[:-1] + (ldx,), dtype=out_dtype, device=y.device)
+    L.check(L.lib().av_log_softmax_bwd_ld(ptr(y), ptr(dy), ptr(dx), dt(dx), y.numel() // cols, cols, ldx, stream()), "av_log_softmax_bwd")
     return dx
 
 
 def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     cols = x.shape[-1]
-    rows = x.numel() // cols
-    assert x.is_contiguous()
+    if x.is_contiguous():
+        rows, ld = x.numel() // cols, cols
+    else:                                                   # a column slice of a wider matrix (rows strided, last dim contiguous)
+        assert x.dim() == 2 and x.stride(1) == 1
+        rows, ld = x.shape[0], x.stride(0)
     if out is None:
         out = torch.empty(cols, dtype=torch.float32, device=x.device)
         accumulate = False
-    L.check(L.lib().av_colsum(ptr(x), dt(x), ptr(out), rows, cols, cols, int(accumulate), stream()), "av_colsum")
+    L.check(L.lib().av_colsum(ptr(x), dt(x), ptr(out), rows, cols, ld, int(accumulate), stream()), "av_colsum")
     return out
 
 
