@@ -230,6 +230,13 @@ def test_log_softmax_colsum_cast():
     dy = _rand(51, 800)
     ref.backward(dy)
     torch.testing.assert_close(ops.log_softmax_bwd(y, dy, torch.float32), xr.grad, rtol=1e-5, atol=1e-5)
+    # K-padded form (CTC head: vocabulary 800 -> 832 columns for the fast GEMM's 64-wide K step): same values, exact zeros in the padding,
+    # and the column sums / dW product of the un-padded view (row stride 832) see only the 800 real columns
+    dp = ops.log_softmax_bwd(y, dy, torch.bfloat16, pad_to=64)
+    assert dp.shape == (51, 832) and float(dp[:, 800:].abs().max()) == 0.0
+    torch.testing.assert_close(dp[:, :800].float(), xr.grad, rtol=2e-2, atol=2e-2)
+    assert torch.equal(dp[:, :800], ops.log_softmax_bwd(y, dy, torch.bfloat16))
+    torch.testing.assert_close(ops.colsum(dp[:, :800]), dp[:, :800].float().sum(0), rtol=1e-3, atol=1e-3)
     big = _rand(1300, 200)
     torch.testing.assert_close(ops.colsum(big), big.sum(0), rtol=1e-4, atol=1e-4)
     odd = _rand(1300, 203)                                                          # cols % 4 != 0: scalar kernel
