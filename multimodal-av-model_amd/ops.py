@@ -33,13 +33,14 @@ def ptr(t: Optional[Tensor]):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def stream():
     """hipStream_t of torch's current stream on the current device (raw handle: ~10x cheaper than building a Stream object
     per kernel launch, which at ~950 launches per step was 3 ms of host time)."""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_cur_dev())                      # torch._C._cuda_getDevice: current_device() without the lazy-init checks
     return torch.cuda.current_stream().cuda_stream
 
 

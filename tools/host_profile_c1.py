@@ -17,6 +17,7 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"host enqueue time per step {(t1 - t0) / 10 * 1e3:.2f} ms, wall per step {(t2 - t0) / 10 * 1e3:.2f} ms")
+torch.autograd.set_multithreading_enabled(False)      # backward functions in this thread: visible to cProfile
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(10):
@@ -24,5 +25,5 @@ for _ in range(10):
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
-print(s.getvalue()[:9000])
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(70)
+print(s.getvalue()[:16000])
