@@ -1187,6 +1187,200 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     AV_STAMP(3);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// v6 (EXPERIMENTAL, off by default: AVAMD_GEMM_V6=1; measured in DESIGN.md section 7): 256 x 256 x 64 tile on FOUR wavefronts (one per SIMD,
+// 512-register budget), each owning 128 x 128 of the tile (8 x 8 MFMA tiles,
+// 256 accumulator registers).  Against the 8-phase kernel: LDS fragment traffic per K-tile 128 KB instead of 196 KB, ONE workgroup
+// barrier per K-tile instead of eight, and every fragment / DMA instruction has a fixed slot in a stream of 16 groups of 8 MFMAs.
+// Two 64 KB stages (A 256 x 64 | B 256 x 64, 128-B rows, 16-B chunks XOR-swizzled with row & 7 on the source side).  Per K-tile t:
+//   groups 0-7   (k-step 0): MFMAs with B set `fb`; each group reads the next A fragment and one B fragment of k-step 1 (`fbn`), and issues
+//                one LDS-DMA instruction of tile t+1's second half;
+//   groups 8-13  (k-step 1): MFMAs with `fbn`; reads of the next A fragment;
+//   barrier:     every wavefront has consumed stage t & 1 (its last two A fragments are in registers) and tile t+1 has landed (vmcnt(0));
+//   groups 14-15: MFMAs of tile t beside the first reads of tile t+1 (B set of k-step 0, first A fragment) and the first half of tile
+//                t+2's LDS-DMA into the stage just freed.
+constexpr int V6_NT = 256, V6_STAGE = 65536, V6_CLD = 260, V6_EPI = 128 * V6_CLD * 4, V6_LDS = V6_EPI;
+
+__global__ __launch_bounds__(V6_NT, 1) void gemm_nt_bf16_v6_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
+    const int ntile = nbM * nbN;
+    int bid = blockIdx.x;
+    {
+        const int q = ntile >> 3, rem = ntile & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * nbN;
+    const int grp = bid / per_group, in_grp = bid - grp * per_group;
+    const int first_m = grp * GM;
+    const int gsz = nbM - first_m < GM ? nbM - first_m : GM;
+    const int mb = first_m + in_grp % gsz, nb = in_grp / gsz;
+    const int m0 = mb * 256, n0 = nb * 256;
+    const int z = blockIdx.z;
+    const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
+    const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
+    const bf16_t* A = (const bf16_t*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
+    const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
+
+    // LDS-DMA sources of my 8 + 8 wave-instructions (8 rows x 128 B each): rows beyond the matrix are clamped (computed, never stored)
+    const bf16_t* pa[8];
+    const bf16_t* pb[8];
+    {
+        const int sub = lane >> 3, choff = ((lane & 7) ^ sub) << 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (w * 8 + i) * 8 + sub;
+            int ga = m0 + row, gb = n0 + row;
+            ga = ga < p.M ? ga : p.M - 1;
+            gb = gb < p.N ? gb : p.N - 1;
+            pa[i] = A + (long long)ga * p.lda + choff;
+            pb[i] = B + (long long)gb * p.ldb + choff;
+        }
+    }
+    const unsigned dst_a = __builtin_amdgcn_readfirstlane((unsigned)(w * 8192)), dst_b = dst_a + 32768u;
+#define V6_DMA(T, Q)                                                                                               \
+    do {                                                                                                           \
+        char* st_ = smem + ((T) & 1) * V6_STAGE;                                                                   \
+        if ((Q) < 8) __builtin_amdgcn_global_load_lds((gptr_t)(pa[(Q) & 7] + (T) * BK), (lptr_t)(st_ + dst_a + ((Q) & 7) * 1024), 16, 0, 0); \
+        else __builtin_amdgcn_global_load_lds((gptr_t)(pb[(Q) & 7] + (T) * BK), (lptr_t)(st_ + dst_b + ((Q) & 7) * 1024), 16, 0, 0);       \
+    } while (0)
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    // prologue: tile 0 and the first half (A rows) of tile 1
+#pragma unroll
+    for (int q = 0; q < 16; ++q) V6_DMA(0, q);
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) V6_DMA(1, q);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const int sw = r & 7;
+    const int ch0 = (g ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
+    const int a_off = (wr * 128 + r) * 128, b_off = 32768 + (wc * 128 + r) * 128;
+#define V6_A(ST, I, CH) (*(const bf16x8*)((ST) + a_off + (I) * 2048 + (CH)))
+#define V6_B(ST, J, CH) (*(const bf16x8*)((ST) + b_off + (J) * 2048 + (CH)))
+#define V6_MMA8(I, FA, FB)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA, FB[j], acc[I][j], 0, 0, 0);
+
+    bf16x8 fb[8], fbn[8], fa0, fa1, fa2;
+    {
+        const char* st = smem;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fb[j] = V6_B(st, j, ch0);
+        fa0 = V6_A(st, 0, ch0);
+    }
+    for (int t = 0; t < nk; ++t) {
+        const char* st = smem + (t & 1) * V6_STAGE;
+        const char* stn = smem + ((t + 1) & 1) * V6_STAGE;
+        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        // ---- k-step 0
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            fa1 = i < 7 ? V6_A(st, i + 1, ch0) : V6_A(st, 0, ch1);
+            fbn[i] = V6_B(st, i, ch1);
+            if (more1) V6_DMA(t + 1, 8 + i);
+            __builtin_amdgcn_sched_barrier(0);
+            V6_MMA8(i, fa0, fb)
+            fa0 = fa1;
+        }
+        // ---- k-step 1, groups 0-5
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            fa1 = V6_A(st, i + 1, ch1);
+            if (i == 5) fa2 = V6_A(st, 7, ch1);
+            __builtin_amdgcn_sched_barrier(0);
+            V6_MMA8(i, fa0, fbn)
+            fa0 = fa1;
+        }
+        // ---- hand-over: stage t & 1 is consumed (fa0 = A(6, 1), fa2 = A(7, 1) are in registers), tile t+1 has landed
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = V6_B(stn, j, ch0);
+        }
+        if (more2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) V6_DMA(t + 2, q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        V6_MMA8(6, fa0, fbn)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) {
+#pragma unroll
+            for (int j = 4; j < 8; ++j) fb[j] = V6_B(stn, j, ch0);
+            fa0 = V6_A(stn, 0, ch0);
+        }
+        if (more2) {
+#pragma unroll
+            for (int q = 4; q < 8; ++q) V6_DMA(t + 2, q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        V6_MMA8(7, fa2, fbn)
+    }
+#undef V6_A
+#undef V6_B
+#undef V6_MMA8
+#undef V6_DMA
+
+    // ---- epilogue: two images of 128 rows x 256 columns (m-tiles 4 h .. 4 h + 3 of every wavefront) through LDS, then 16-B rows
+    float* cs = (float*)smem;
+    const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
+    const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
+    const float* bias = p.bias ? p.bias + (long long)zi * p.sBias : nullptr;
+    constexpr int CPR = 32;
+    float bv[8];
+    {
+        const int gnt = n0 + (tid % CPR) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (bias && gnt + e < p.N) ? bias[gnt + e] : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cs[(wr * 64 + i * 16 + 4 * g + e) * V6_CLD + wc * 128 + j * 16 + r] = acc[4 * h + i][j][e] * p.alpha;
+        __syncthreads();
+        for (int it = 0; it < 128 * CPR / V6_NT; ++it) {
+            const int id = it * V6_NT + tid;
+            const int row = id / CPR, cc = (id % CPR) * 8;
+            const int gm = m0 + (row >> 6) * 128 + h * 64 + (row & 63), gn = n0 + cc;
+            if (gm >= p.M || gn >= p.N) continue;
+            float v[8];
+            const f32x4 v0 = *(const f32x4*)(cs + row * V6_CLD + cc), v1 = *(const f32x4*)(cs + row * V6_CLD + cc + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
+            const bool full = gn + 8 <= p.N;
+            const long long off = cbase + (long long)gm * p.ldc + gn;
+            epilogue_store(p, fl, v, off, gm, gn, full, R);
+        }
+    }
+}
+
 template <int BNT, bool CONV, bool AKM = false, bool BKM = false>
 int launch_fast(const av_gemm_args& p, hipStream_t st, const FastFlags& fl) {
     constexpr int STAGE = TILE_A + BNT * BK * 2;
@@ -1260,6 +1454,21 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         }
         const int nbM = av_cdiv(p.M, V4_BM), nbN = av_cdiv(p.N, V4_BN);
         hipLaunchKernelGGL(gemm_nt_bf16_v4_kernel<true>, dim3((unsigned)(nbM * nbN), 1, 1), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl, nbM * nbN, V4_BM);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
+    static const int v6_mode = [] { const char* e = getenv("AVAMD_GEMM_V6"); return e ? atoi(e) : 0; }();
+    if (v6_mode > 0 && !conv && !narrow && p.M >= 256 && p.N >= 256 && !p.stats) {
+        static bool v6_attr = false;
+        if (!v6_attr) {
+            if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V6_LDS) != hipSuccess) {
+                av_set_error("av_gemm(fast v6): cannot raise dynamic LDS to %d", V6_LDS);
+                return AV_ERR_LAUNCH;
+            }
+            v6_attr = true;
+        }
+        const int nbM = av_cdiv(p.M, 256), nbN = av_cdiv(p.N, 256);
+        hipLaunchKernelGGL(gemm_nt_bf16_v6_kernel, dim3((unsigned)(nbM * nbN), 1, (unsigned)p.batch), dim3(V6_NT), V6_LDS, st, p, nbM, nbN, fl);
         AV_LAUNCH_CHECK();
         return AV_OK;
     }

@@ -566,3 +566,30 @@ def test_class_order_equals_stable_argsort_of_the_class_rank(n):
     L.check(L.lib().av_class_order(ops.ptr(m), n, ops.ptr(order), ops.stream()))
     rank = torch.tensor([2, 0, 1, 3])[mask.clamp(0, 3)]
     assert torch.equal(order.cpu(), torch.argsort(rank, stable=True))
+
+
+def test_four_wavefront_gemm_kernel_behind_its_switch():
+    """gemm_nt_bf16_v6_kernel (experimental, AVAMD_GEMM_V6=1; the switch is read once per process, hence the child process): plain, bias +
+    GELU and fp32 + residual epilogues at a ragged M / N against fp32 torch."""
+    import os, subprocess, sys
+    code = r'''
+import importlib, sys, torch
+sys.path.insert(0, %r)
+ops = importlib.import_module("multimodal-av-model_amd.ops"); L = importlib.import_module("multimodal-av-model_amd._lib")
+torch.manual_seed(0)
+for (M, N, K) in ((1000, 520, 192), (2048, 1024, 1024), (300, 264, 64)):
+    a = (torch.rand(M, K, device="cuda") - 0.5).to(torch.bfloat16); w = (torch.rand(N, K, device="cuda") - 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda"); r = torch.randn(M, N, device="cuda")
+    ref = a.float() @ w.float().t()
+    y = ops.linear(a, w, out_dtype=torch.float32)
+    assert (y - ref).abs().max() < 2e-3 * K ** 0.5, ("plain", M, N, K, float((y - ref).abs().max()))
+    y = ops.linear(a, w, b, out_dtype=torch.float32, R=r)
+    assert (y - (ref + b + r)).abs().max() < 2e-3 * K ** 0.5, ("bias+res", M, N, K)
+    y = ops.linear(a, w, b, act=L.ACT_GELU)
+    g = torch.nn.functional.gelu(ref + b)
+    assert (y.float() - g).abs().max() < 3e-2 * max(1.0, float(g.abs().max())), ("gelu", M, N, K)
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVAMD_GEMM_V6="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
