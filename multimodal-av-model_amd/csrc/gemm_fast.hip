@@ -1204,6 +1204,7 @@ constexpr int V6_NT = 256, V6_STAGE = 65536, V6_CLD = 260, V6_EPI = 128 * V6_CLD
 
 __global__ __launch_bounds__(V6_NT, 1) void gemm_nt_bf16_v6_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    AV_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1, r = lane & 15, g = lane >> 4;
     const int ntile = nbM * nbN;
@@ -1267,6 +1268,7 @@ __global__ __launch_bounds__(V6_NT, 1) void gemm_nt_bf16_v6_kernel(const av_gemm
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    AV_STAMP(1);
 
     const int sw = r & 7;
     const int ch0 = (g ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
@@ -1341,6 +1343,7 @@ __global__ __launch_bounds__(V6_NT, 1) void gemm_nt_bf16_v6_kernel(const av_gemm
 #undef V6_B
 #undef V6_MMA8
 #undef V6_DMA
+    AV_STAMP(2);
 
     // ---- epilogue: two images of 128 rows x 256 columns (m-tiles 4 h .. 4 h + 3 of every wavefront) through LDS, then 16-B rows
     float* cs = (float*)smem;
@@ -1365,20 +1368,31 @@ __global__ __launch_bounds__(V6_NT, 1) void gemm_nt_bf16_v6_kernel(const av_gemm
                 for (int e = 0; e < 4; ++e)
                     cs[(wr * 64 + i * 16 + 4 * g + e) * V6_CLD + wc * 128 + j * 16 + r] = acc[4 * h + i][j][e] * p.alpha;
         __syncthreads();
+        // one wavefront per SIMD: nothing else hides the LDS round trip of a row chunk, so the next chunk's reads are issued before this one
+        // is processed (rolled loop: the shared store tail is instantiated once)
+        const int cc = (tid % CPR) * 8, gn = n0 + cc, row0 = tid / CPR;            // rows row0 + 8 it
+        const bool full = gn + 8 <= p.N;
+        f32x4 n0v = *(const f32x4*)(cs + row0 * V6_CLD + cc), n1v = *(const f32x4*)(cs + row0 * V6_CLD + cc + 4);
         for (int it = 0; it < 128 * CPR / V6_NT; ++it) {
-            const int id = it * V6_NT + tid;
-            const int row = id / CPR, cc = (id % CPR) * 8;
-            const int gm = m0 + (row >> 6) * 128 + h * 64 + (row & 63), gn = n0 + cc;
+            const int row = row0 + it * (V6_NT / CPR);
+            const f32x4 v0 = n0v, v1 = n1v;
+            if (it + 1 < 128 * CPR / V6_NT) {
+                n0v = *(const f32x4*)(cs + (row + V6_NT / CPR) * V6_CLD + cc);
+                n1v = *(const f32x4*)(cs + (row + V6_NT / CPR) * V6_CLD + cc + 4);
+            }
+            const int gm = m0 + (row >> 6) * 128 + h * 64 + (row & 63);
             if (gm >= p.M || gn >= p.N) continue;
             float v[8];
-            const f32x4 v0 = *(const f32x4*)(cs + row * V6_CLD + cc), v1 = *(const f32x4*)(cs + row * V6_CLD + cc + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
-            const bool full = gn + 8 <= p.N;
             const long long off = cbase + (long long)gm * p.ldc + gn;
             epilogue_store(p, fl, v, off, gm, gn, full, R);
         }
     }
+#ifdef AV_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    AV_STAMP(3);
 }
 
 template <int BNT, bool CONV, bool AKM = false, bool BKM = false>
