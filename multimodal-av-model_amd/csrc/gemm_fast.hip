@@ -823,9 +823,18 @@ __global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm
 constexpr int V4_BM = 256, V4_BN = 256, V4_NT = 512;
 constexpr int V4_HALF = 128 * BK * 2;                       // 16 384 B: one half-tile slot (128 rows x 128 B)
 constexpr int V4_KT = 4 * V4_HALF;                          // 65 536 B per K-tile
+// Ring of V4_NS half-tile slots, LDS-DMA issued V4_NS - 2 half-tiles ahead of the one being consumed (the slot overwritten at phase p of K-tile
+// t is always the one of half-tile 4 t + p - 2, for any ring size).  8 slots = two K-tiles (96 KB in flight at most); 10 slots = all 160 KB
+// of the CU's LDS, 128 KB in flight: with every CU busy the L2 -> LDS stream (44 GB/s per CU) needs more than 96 KB outstanding to cover its
+// latency.  -DAV_V4_NS=8 builds the old ring (A/B).
+#ifndef AV_V4_NS
+#define AV_V4_NS 10
+#endif
+constexpr int V4_NS = AV_V4_NS, V4_LEAD = V4_NS - 2;
+static_assert(V4_NS == 8 || V4_NS == 10, "ring of 8 or 10 half-tile slots");
 constexpr int V4_CLD = V4_BN + 4;
 constexpr int V4_EPI = 128 * V4_CLD * 4;                    // 133 120 B
-constexpr int V4_LDS = V4_EPI + 4096;                       // image (> the two K-tile rings) + BatchNorm partial scratch
+constexpr int V4_LDS = V4_NS * V4_HALF > V4_EPI + 4096 ? V4_NS * V4_HALF : V4_EPI + 4096;   // ring | epilogue image + BatchNorm partial scratch
 
 // Tail jobs of the v4 grid: ONE 128 x 128 quadrant of a 256 x 256 tile per workgroup (same wavefront layout: 2 x 4, 64 x 32 each, 32
 // accumulator registers).  When the tile count leaves a short last round (R = tiles mod 256 <= 128), those R tiles are cut into 4 R
@@ -1029,11 +1038,11 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         if (p.cPM) { ts = tap_seq(p, m0, V4_BM); if (ts.ntap >= 0) nk = ts.ntap << ts.sh; }       // taps outside the image for this tile's position: skipped
     }
     const int nh = 4 * nk;                                   // half-tiles in issue order: slot j = s & 3 : 0 = A0, 1 = B1, 2 = A1, 3 = B0
-    auto issue = [&](int t, int j) {                         // j is a compile-time constant at every call site
+    auto issue = [&](int t, int j, int sidx) {               // half-tile 4 t + j into ring slot sidx = (4 t + j) % V4_NS; j is a compile-time constant
 #ifdef AV_ABL_NODMA
         return;
 #endif
-        char* slot = smem + (t & 1) * V4_KT + j * V4_HALF;
+        char* slot = smem + sidx * V4_HALF;
         int k0 = t * BK;
         if constexpr (CONV) k0 = tap_k0(p, ts, t);
         if (j == 0) { if constexpr (CONV) stage_conv2(p, cr0, k0, slot, w, lane); else stage_rows<2>(A, p.lda, m0, p.M, k0, slot, w, lane); }
@@ -1041,10 +1050,13 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         else if (j == 3) stage_rows<2>(B, p.ldb, n0, p.N, k0, slot, w, lane);
         else stage_rows<2>(B, p.ldb, n0 + 128, p.N, k0, slot, w, lane);
     };
-    // prologue: half-tiles 0..5 (K-tile 0 and A0, B1 of K-tile 1)
-    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
-    if (nk > 1) { issue(1, 0); issue(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue: half-tiles 0 .. V4_LEAD - 1 (K-tile 0 and the first half-tiles of the next ones); K-tile 0 must have landed
+    issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); issue(0, 3, 3);
+    if (nk > 1) {
+        issue(1, 0, 4); issue(1, 1, 5);
+        if constexpr (V4_LEAD == 8) { issue(1, 2, 6); issue(1, 3, 7); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                            // K-tile 0 landed for everyone
     asm volatile("" ::: "memory");
     if (wr == 1) __builtin_amdgcn_s_barrier();       // wavefronts 4-7 run one barrier behind
@@ -1065,12 +1077,12 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #endif
 #define V4_READ_A(SLOT, NMT)                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < (NMT)) {                                                 \
-        fa[i][0] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + a_row + i * 2048 + ch0);                               \
-        fa[i][1] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + a_row + i * 2048 + ch1); }
+        fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch0);                           \
+        fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch1); }
 #define V4_READ_B(SLOT)                                                                                            \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
-        fb[j][0] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + b_row + j * 2048 + ch0);                               \
-        fb[j][1] = *(const bf16x8*)(kb + (SLOT) * V4_HALF + b_row + j * 2048 + ch1); }
+        fb[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                           \
+        fb[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); }
 #define V4_MMA(QA, QB)                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
@@ -1085,26 +1097,35 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     __builtin_amdgcn_s_barrier();                                                                                  \
     asm volatile("" ::: "memory");
 
+    int b4 = 0;                                              // (4 t) % V4_NS: ring slot of half-tile (t, 0)
     for (int t = 0; t < nk; ++t) {
-        const char* kb = smem + (t & 1) * V4_KT;
+        int sl[4], si[4];                                    // slots of this K-tile's half-tiles; slots the four phases refill (half-tile 4 t + V4_LEAD + p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int x = b4 + j; x = x >= V4_NS ? x - V4_NS : x; sl[j] = x;
+            int y = b4 + j - 2; y = y < 0 ? y + V4_NS : y; si[j] = y;
+        }
+        b4 += 4; b4 = b4 >= V4_NS ? b4 - V4_NS : b4;
         // phase 0: quadrant (A0, B0)
         V4_READ_B(3)
         __builtin_amdgcn_sched_barrier(0);
         V4_READ_A(0, nmt0)
-        if (4 * t + 6 < nh) issue(t + 1, 2);
+        if (4 * t + V4_LEAD + 0 < nh) issue(t + (V4_LEAD + 0) / 4, (V4_LEAD + 0) % 4, si[0]);
         V4_MMA(0, 0)
         // phase 1: (A0, B1)
         V4_READ_B(1)
-        if (4 * t + 7 < nh) issue(t + 1, 3);
+        if (4 * t + V4_LEAD + 1 < nh) issue(t + (V4_LEAD + 1) / 4, (V4_LEAD + 1) % 4, si[1]);
         V4_MMA(0, 1)
         // phase 2: (A1, B1)
         V4_READ_A(2, nmt1)
-        if (4 * t + 8 < nh) issue(t + 2, 0);
+        if (4 * t + V4_LEAD + 2 < nh) issue(t + (V4_LEAD + 2) / 4, (V4_LEAD + 2) % 4, si[2]);
         V4_MMA(1, 1)
-        // phase 3: (A1, B0); the K-tile's one counted wait: all of K-tile t+1 has landed, the two youngest half-tiles (t+2) may fly
+        // phase 3: (A1, B0); the K-tile's one counted wait: all of K-tile t+1 has landed, the V4_LEAD - 4 youngest half-tiles (t+2) may fly
         V4_READ_B(3)
-        if (4 * t + 9 < nh) { issue(t + 2, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (4 * t + V4_LEAD + 3 < nh) {
+            issue(t + (V4_LEAD + 3) / 4, (V4_LEAD + 3) % 4, si[3]);
+            if constexpr (V4_LEAD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         V4_MMA(1, 0)
     }
 #undef V4_READ_A
