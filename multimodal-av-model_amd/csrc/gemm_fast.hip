@@ -192,8 +192,14 @@ __device__ __forceinline__ void stage_conv(const av_gemm_args& p, const ConvRows
 struct FastFlags { int c_vec, r_vec, aux_vec; };
 
 // shared tail of the coalesced epilogue: optional pre-activation copy, activation, dropout, residual, store (8 columns)
-__device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const FastFlags& fl, float (&v)[8], long long off, int gm, int gn, bool full,
-                                               const float* R) {
+// VO ("vector only", v7's specialised instantiations): the caller guarantees whole, 16-B aligned chunks for C / C2 / R / aux (N % 8 == 0 and the
+// FastFlags all set), so the element-wise fallbacks are not generated
+template <bool VO>
+__device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const FastFlags& fl0, float (&v)[8], long long off, int gm, int gn, bool full0,
+                                                 const float* R) {
+    const bool full = VO ? true : full0;
+    FastFlags fl = fl0;
+    if constexpr (VO) { fl.c_vec = 1; fl.r_vec = 1; fl.aux_vec = 1; }
     if (p.act == AV_ACT_GELU_GF) {
         // activation + dropout site whose backward is a plain multiply: C2 = gelu'(v) * m, v = gelu(v) * m (m = dropout multiplier); the dX
         // product of the layer above then ends in AV_ACT_MUL_AUX - no erf / exp / Philox while its matrix pipe waits
@@ -316,6 +322,11 @@ __device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const Fast
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C, off + e, p.out_dtype, v[e]);
     }
+}
+
+__device__ __forceinline__ void epilogue_store(const av_gemm_args& p, const FastFlags& fl, float (&v)[8], long long off, int gm, int gn, bool full,
+                                               const float* R) {
+    epilogue_store_t<false>(p, fl, v, off, gm, gn, full, R);
 }
 
 
@@ -1210,6 +1221,272 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
+// v7: the 8-phase kernel above as a PERSISTENT workgroup with a register-direct epilogue (plain NT products; not CONV).
+//   * one workgroup per CU walks its list of 256 x 256 tiles (the same XCD-aware order the dispatcher gave the v4 grid: XCD label = block id
+//     mod 8 owns a contiguous range of tile ids, its workgroups take every S-th of them); the short last round still runs as quadrant jobs;
+//   * the MFMA operands are swapped (D = B-fragment x A-fragment): a lane then holds 4 CONSECUTIVE COLUMNS of one output row per accumulator
+//     instead of 4 rows of one column, and the B half-tiles are staged with their rows permuted (LDS row [wc:2][j:1][g:2][e:2] of half b holds
+//     tile column wc 64 + b 32 + g 8 + j 4 + e; the permutation sits on the LDS-DMA source address, fragment reads and their bank pattern are
+//     unchanged) so that the two n-tiles of a lane are adjacent: a lane owns 8 consecutive columns = one 16-B (bf16) / two 16-B (fp32) stores,
+//     a wavefront instruction writes 16 rows x 64 B and the two B halves complete the 128-B lines.  The epilogue therefore needs NO LDS image
+//     and no barrier: bias / activation / dropout / residual run on the accumulator registers (same operation order per element as the
+//     image epilogue: results are bit-identical to the v4 kernel);
+//   * with the ring free at the end of the main loop, the first V4_LEAD half-tiles of the workgroup's NEXT tile are requested before the
+//     epilogue of the current one and land while it computes and stores: a tile no longer starts with an empty ring (v4: 1.8 us entry +
+//     cold first K-tiles per tile), and the stores of tile i drain under the main loop of tile i + 1 (vmcnt counts loads, LDS-DMA and stores
+//     in one in-order counter: every counted wait of the loop only ever waits for MORE than it needs, never less).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int v7_bcol(int rho, int b) {    // LDS row of B half-tile b -> column of the 256-wide block tile
+    return ((rho >> 5) << 6) | (b << 5) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3);
+}
+__device__ __forceinline__ void v7_stage_b(const bf16_t* __restrict__ base, long long ld, int n0, int nrows, int k0, char* tile, int w, int lane, int b) {
+    const int sub = lane >> 3, pch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rho = (w * 2 + i) * 8 + sub;
+        int gr = n0 + v7_bcol(rho, b);
+        if (gr > nrows - 1) gr = nrows - 1;                      // clamped columns are computed but never stored
+        const bf16_t* src = base + (long long)gr * ld + k0 + ((pch ^ sub) << 3);
+        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 2 + i) * 1024));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+    }
+}
+
+// one 8-column chunk of a lane: c0 / c1 = the accumulators of n-tiles j = 0 / 1 (columns gn .. gn + 3 / gn + 4 .. gn + 7 of row gm)
+template <bool VO>
+__device__ __forceinline__ void v7_chunk(const av_gemm_args& p, const FastFlags& fl, const f32x4& c0, const f32x4& c1, const float (&bv)[8],
+                                         int gm, int gn, int m_end, long long cbase, const float* R) {
+    if (gm >= m_end || gn >= p.N) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = c0[e] * p.alpha + bv[e]; v[4 + e] = c1[e] * p.alpha + bv[4 + e]; }
+    epilogue_store_t<VO>(p, fl, v, cbase + (long long)gm * p.ldc + gn, gm, gn, gn + 8 <= p.N, R);
+}
+
+// ACT / ODT >= 0: the activation / output type are compile-time constants of this instantiation (the epilogue body shrinks to what the class
+// needs); -1: read from the arguments at run time.  VO: see epilogue_store_t.
+template <int ACT, int ODT, bool VO>
+__global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm_args pa, const int nbM, const int nbN, const FastFlags fl, const int nfull, const int bm_eff) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(V4_LEAD == 8, "v7 assumes the 10-slot ring");
+    av_gemm_args p = pa;
+    if constexpr (ACT >= 0) p.act = ACT;
+    if constexpr (ODT >= 0) p.out_dtype = ODT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = __builtin_amdgcn_readfirstlane(w >> 2), wc = w & 3;
+    const int r = lane & 15, g = lane >> 4;
+    const int ntile = nbM * nbN;
+    // my share of the full tiles: XCD label x owns ids [cs, cs + cn) (bijective split of [0, nfull)), its S workgroups take local ids slot, slot + S, ...
+    const int G = (int)gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int S = (G - xcd + 7) >> 3;
+    int cs, cn;
+    { const int q = nfull >> 3, rem = nfull & 7; cn = q + (xcd < rem ? 1 : 0); cs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q; }
+    auto coords = [&](int id, int& m0, int& n0, int& mb) {
+        constexpr int GM = 4;
+        const int per_group = GM * nbN;
+        const int grp = id / per_group, in_grp = id - grp * per_group;
+        const int first_m = grp * GM;
+        const int gsz = nbM - first_m < GM ? nbM - first_m : GM;
+        mb = first_m + in_grp % gsz;
+        m0 = mb * bm_eff; n0 = (in_grp / gsz) * V4_BN;
+    };
+    const int z = blockIdx.z;
+    const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
+    const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
+    const bf16_t* A = (const bf16_t*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
+    const bf16_t* B = (const bf16_t*)p.B + (long long)zo * p.oB + (long long)zi * p.sB;
+    const long long cbase = (long long)zo * p.oC + (long long)zi * p.sC;
+    const float* R = p.R ? p.R + (long long)zi * p.sR : nullptr;
+    const float* bias = p.bias ? p.bias + (long long)zi * p.sBias : nullptr;
+    const int nk = p.K / BK, nh = 4 * nk;
+
+    // half-tile (t, j) of the tile at (tm0, tn0) into ring slot sidx; j: 0 = A0, 1 = B1, 2 = A1, 3 = B0 (compile-time constant at every call)
+    auto issue = [&](int tm0, int tn0, int t, int j, int sidx) {
+        char* sl_ = smem + sidx * V4_HALF;
+        const int k0 = t * BK;
+        if (j == 0) stage_rows<2>(A, p.lda, tm0, p.M, k0, sl_, w, lane);
+        else if (j == 2) stage_rows<2>(A, p.lda, tm0 + 128, p.M, k0, sl_, w, lane);
+        else if (j == 3) v7_stage_b(B, p.ldb, tn0, p.N, k0, sl_, w, lane, 0);
+        else v7_stage_b(B, p.ldb, tn0, p.N, k0, sl_, w, lane, 1);
+    };
+    auto prefetch = [&](int tm0, int tn0) {                  // ring slots 0 .. 7 <- K-tile 0 and (if any) K-tile 1
+        issue(tm0, tn0, 0, 0, 0); issue(tm0, tn0, 0, 1, 1); issue(tm0, tn0, 0, 2, 2); issue(tm0, tn0, 0, 3, 3);
+        if (nk > 1) { issue(tm0, tn0, 1, 0, 4); issue(tm0, tn0, 1, 1, 5); issue(tm0, tn0, 1, 2, 6); issue(tm0, tn0, 1, 3, 7); }
+    };
+    // bias of my 16 columns of a tile: [b][8]
+    auto load_bias = [&](int tn0, float (&bb)[2][8]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int gn = tn0 + wc * 64 + b * 32 + g * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bb[b][e] = (bias && gn + e < p.N) ? bias[gn + e] : 0.f;
+        }
+    };
+
+    const int sw = r & 7;
+    const int ch0 = (g ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
+    const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
+
+    int li = slot;
+    int m0 = 0, n0 = 0, mb = 0;
+    float bnext[2][8];                                       // bias of the tile whose ring prefetch is in flight (loop-carried)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bnext[b][e] = 0.f;
+    if (li < cn) {
+        coords(cs + li, m0, n0, mb);
+        prefetch(m0, n0);
+        load_bias(n0, bnext);
+    }
+    while (li < cn) {
+        const int nli = li + S;
+        const bool has_next = nli < cn;
+        int nm0 = 0, nn0 = 0, nmb = 0;
+        if (has_next) coords(cs + nli, nm0, nn0, nmb);
+        const int rows_here = p.M - m0 < bm_eff ? p.M - m0 : bm_eff;
+        auto ntiles = [&](int start) { int n = (rows_here - start + 15) >> 4; return n < 0 ? 0 : (n > 4 ? 4 : n); };
+        const int nmt0 = __builtin_amdgcn_readfirstlane(ntiles(wr * 64)), nmt1 = __builtin_amdgcn_readfirstlane(ntiles(128 + wr * 64));
+
+        f32x4 acc[2][2][4][2];                               // [A half][B half][m-tile][n-tile]; lane (g, r): row r of the m-tile, n-tile columns 4 g + e
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // K-tile 0 (the 8 oldest LDS-DMA instructions of this tile; anything older - the previous tile's stores - has completed too)
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the bias loads of this tile were issued with its prefetch: consume them HERE (the compiler's wait for them lands beside the wait
+        // above, not in the epilogue behind the next tile's just-issued LDS-DMA)
+        float bcur[2][8];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { asm volatile("" : "+v"(bnext[b][e])); bcur[b][e] = bnext[b][e]; }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wr == 1) __builtin_amdgcn_s_barrier();           // wavefronts 4-7 run one barrier behind
+
+        bf16x8 fa[4][2], fb[2][2];
+#define V7_READ_A(SLOT, NMT)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < (NMT)) {                                                 \
+        fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch0);                           \
+        fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch1); }
+#define V7_READ_B(SLOT)                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
+        fb[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                           \
+        fb[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); }
+#define V7_MMA(QA, QB)                                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < ((QA) ? nmt1 : nmt0))                                \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    asm volatile("" ::: "memory");
+
+        int b4 = 0;                                          // (4 t) % V4_NS: ring slot of half-tile (t, 0)
+        for (int t = 0; t < nk; ++t) {
+            int sl[4], si[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int x = b4 + j; x = x >= V4_NS ? x - V4_NS : x; sl[j] = x;
+                int y = b4 + j - 2; y = y < 0 ? y + V4_NS : y; si[j] = y;
+            }
+            b4 += 4; b4 = b4 >= V4_NS ? b4 - V4_NS : b4;
+            V7_READ_B(3)
+            __builtin_amdgcn_sched_barrier(0);
+            V7_READ_A(0, nmt0)
+            if (4 * t + V4_LEAD + 0 < nh) issue(m0, n0, t + 2, 0, si[0]);
+            V7_MMA(0, 0)
+            V7_READ_B(1)
+            if (4 * t + V4_LEAD + 1 < nh) issue(m0, n0, t + 2, 1, si[1]);
+            V7_MMA(0, 1)
+            V7_READ_A(2, nmt1)
+            if (4 * t + V4_LEAD + 2 < nh) issue(m0, n0, t + 2, 2, si[2]);
+            V7_MMA(1, 1)
+            V7_READ_B(3)
+            if (4 * t + V4_LEAD + 3 < nh) {
+                issue(m0, n0, t + 2, 3, si[3]);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            V7_MMA(1, 0)
+        }
+#undef V7_READ_A
+#undef V7_READ_B
+#undef V7_MMA
+        if (wr == 0) __builtin_amdgcn_s_barrier();           // balance the entry barrier of wavefronts 4-7: every fragment read of this tile has completed
+        asm volatile("" ::: "memory");
+
+        // the ring is free: request the next tile's first two K-tiles, then store this tile from the registers
+        if (has_next) { prefetch(nm0, nn0); load_bias(nn0, bnext); }
+        const int m_end = m0 + rows_here;
+        {
+            // ONE copy of the epilogue body for four m-tiles (code size: it is inlined with every activation / dropout / residual branch).  The
+            // quadrants (a, b) = (0,0) (0,1) (1,0) (1,1) pass through the registers of quadrant (0,0) - dead once stored - and the two bias
+            // windows swap, so the rolled loop costs no registers
+            float bv[8], bo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bv[e] = bcur[0][e]; bo[e] = bcur[1][e]; }
+#pragma unroll 1
+            for (int qd = 0; qd < 4; ++qd) {
+                const int a = qd >> 1, b = qd & 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v7_chunk<VO>(p, fl, acc[0][0][i][0], acc[0][0][i][1], bv, m0 + a * 128 + wr * 64 + i * 16 + r, n0 + wc * 64 + b * 32 + g * 8, m_end, cbase, R);
+                if (qd == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[0][0][i][j] = acc[0][1][i][j];
+                } else if (qd == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[0][0][i][j] = acc[1][0][i][j];
+                } else if (qd == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[0][0][i][j] = acc[1][1][i][j];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float t = bv[e]; bv[e] = bo[e]; bo[e] = t; }
+            }
+        }
+        li = nli; m0 = nm0; n0 = nn0; mb = nmb;
+    }
+
+    // the short last round: quadrant jobs (v4's scheme, image epilogue), spread over the same persistent workgroups
+    const int nq = 4 * (ntile - nfull);
+    if (nq > 0) {
+        int qs, qn_;
+        { const int q = nq >> 3, rem = nq & 7; qn_ = q + (xcd < rem ? 1 : 0); qs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q; }
+        for (int lj = slot; lj < qn_; lj += S) {
+            const int j = qs + lj;
+            int tm0, tn0, tmb;
+            coords(nfull + (j >> 2), tm0, tn0, tmb);
+            const int quad = j & 3;
+            const int rows_here = p.M - tm0 < bm_eff ? p.M - tm0 : bm_eff;
+            const int qm = tm0 + (quad >> 1) * 128, qn = tn0 + (quad & 1) * 128;
+            __syncthreads();                                 // (also retires this workgroup's outstanding stores: __syncthreads waits vmcnt(0))
+            if (qm < tm0 + rows_here && qn < p.N)            // block-uniform
+                v4_quadrant_job(p, fl, smem, A, B, qm, qn, tm0 + rows_here, cbase, R, bias);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
 // v6 (EXPERIMENTAL, off by default: AVAMD_GEMM_V6=1; measured in DESIGN.md section 7): 256 x 256 x 64 tile on FOUR wavefronts (one per SIMD,
 // 512-register budget), each owning 128 x 128 of the tile (8 x 8 MFMA tiles,
 // 256 accumulator registers).  Against the 8-phase kernel: LDS fragment traffic per K-tile 128 KB instead of 196 KB, ONE workgroup
@@ -1528,6 +1805,45 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         const long long t1 = (long long)av_cdiv(p.M, BM) * av_cdiv(p.N, 128) * p.batch;
         const double e2 = (double)((t2 + 255) / 256) * (nk * 0.85 + 2.0);
         const double e1 = (double)((t1 + 511) / 512) * (nk * 1.0 + 2.5);
+        static const int v7_mode = [] { const char* e = getenv("AVAMD_GEMM_V7"); return e ? atoi(e) : 1; }();
+        // persistent form (see the kernel's notes): specialised per epilogue class; the classes need whole 16-B chunks everywhere
+        // (epilogue_store_t<true>) - anything else stays on the v4 kernel
+        const bool v7_vo = p.N % 8 == 0 && fl.c_vec && (!p.R || fl.r_vec) && (!p.aux || fl.aux_vec);
+        const bool v7_cls = (p.out_dtype == AV_BF16 && (p.act == AV_ACT_NONE || p.act == AV_ACT_GELU || p.act == AV_ACT_GELU_GF || p.act == AV_ACT_MUL_AUX)) ||
+                            (p.out_dtype == AV_F32 && p.act == AV_ACT_NONE);
+        if (v7_mode > 0 && v7_vo && v7_cls && (v7_mode >= 2 || v4_mode >= 2 || e4 < (v2_ok ? (e2 < e1 ? e2 : e1) : e1))) {
+            static int ncu = 0;
+            if (!ncu) {
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+            }
+            const int nbM = av_cdiv(p.M, best_bm);
+            const int ntile = nbM * nbN4;
+            int nfull = ntile;
+            if (p.batch == 1 && v4_tail && ntile > ncu) { const int r = ntile % ncu; if (r > 0 && r <= ncu / 2) nfull = ntile - r; }
+            const int G = ntile < ncu ? ntile : ncu;
+            int rc = AV_OK;
+            auto go = [&](auto kern) {
+                static bool attr = false;                    // one flag per instantiation (the lambda's call operator is a template)
+                if (!attr) {
+                    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS) != hipSuccess) {
+                        av_set_error("av_gemm(fast v7): cannot raise dynamic LDS to %d", V4_LDS);
+                        rc = AV_ERR_LAUNCH;
+                        return;
+                    }
+                    attr = true;
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)G, 1, (unsigned)p.batch), dim3(V4_NT), V4_LDS, st, p, nbM, nbN4, fl, nfull, best_bm);
+            };
+            if (p.out_dtype == AV_F32) go(gemm_nt_bf16_v7_kernel<AV_ACT_NONE, AV_F32, true>);
+            else if (p.act == AV_ACT_NONE) go(gemm_nt_bf16_v7_kernel<AV_ACT_NONE, AV_BF16, true>);
+            else if (p.act == AV_ACT_GELU) go(gemm_nt_bf16_v7_kernel<AV_ACT_GELU, AV_BF16, true>);
+            else if (p.act == AV_ACT_GELU_GF) go(gemm_nt_bf16_v7_kernel<AV_ACT_GELU_GF, AV_BF16, true>);
+            else go(gemm_nt_bf16_v7_kernel<AV_ACT_MUL_AUX, AV_BF16, true>);
+            if (rc != AV_OK) return rc;
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
         if (v4_mode >= 2 || e4 < (v2_ok ? (e2 < e1 ? e2 : e1) : e1)) {
             static bool v4_attr = false;
             if (!v4_attr) {

@@ -1,0 +1,48 @@
+"""v7 (persistent, register-direct epilogue) against v4 (AVAMD_GEMM_V7=0): `save` writes the outputs of every epilogue class on shapes with
+several tiles per workgroup / a quadrant tail / ragged edges, `compare` checks the current mode against them bit for bit."""
+import importlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ops = importlib.import_module("multimodal-av-model_amd.ops"); L = importlib.import_module("multimodal-av-model_amd._lib")
+mode, path = sys.argv[1], sys.argv[2]
+drop = (0.1, 1234, 5)
+SHAPES = [(12736, 4096, 1024), (12736, 3072, 1024), (12736, 1024, 4096), (12736, 1024, 1024), (4400, 4328, 192), (3800, 8192, 128), (2048, 512, 64),
+          (1500, 768, 320), (70000, 512, 128), (12736, 1000, 256)]
+
+
+def outputs(M, N, K):
+    g = torch.Generator(device="cuda"); g.manual_seed(M * 7 + N * 3 + K)
+    a = (torch.rand(M, K, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16); w = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g); r = torch.randn(M, N, device="cuda", generator=g); aux = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    o = {}
+    o["plain"] = ops.linear(a, w, None)
+    o["bias"] = ops.linear(a, w, b)
+    o["gelu_drop"] = ops.linear(a, w, b, act=L.ACT_GELU, drop=drop)
+    c2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    o["gelu_gf"] = ops.linear(a, w, b, act=L.ACT_GELU_GF, C2=c2, drop=drop); o["gelu_gf_c2"] = c2
+    o["mul_aux"] = ops.linear(a, w, None, act=L.ACT_MUL_AUX, aux=aux)
+    o["res_f32_drop"] = ops.linear(a, w, b, out_dtype=torch.float32, R=r, drop=drop)
+    o["res_f32_alpha"] = ops.linear(a, w, b, out_dtype=torch.float32, R=r, alpha=0.5)
+    o["f32"] = ops.linear(a, w, None, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    return {k: v.cpu() for k, v in o.items()}
+
+
+res = {}
+bad = 0
+ref = torch.load(path) if mode == "compare" else None
+for s in SHAPES:
+    o = outputs(*s)
+    if mode == "save":
+        res[s] = o
+    else:
+        for k, v in o.items():
+            same = torch.equal(v, ref[s][k])
+            if not same:
+                d = (v.float() - ref[s][k].float()).abs()
+                print("MISMATCH", s, k, "max", float(d.max()), "count", int((d > 0).sum()), "of", d.numel(), flush=True); bad += 1
+        print("checked", s, flush=True)
+if mode == "save":
+    torch.save(res, path); print("saved", len(res))
+else:
+    print("bit-identical" if bad == 0 else f"{bad} mismatching outputs")
+    sys.exit(1 if bad else 0)
