@@ -31,8 +31,12 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_line[256];   // so
 #ifdef AV_GEMM_STAMPS
 __device__ unsigned long long g_gemm_stamps[8192 * 4];
 #define AV_STAMP(SLOT) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 4 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// persistent kernel (v7): [workgroup < 256][tile of the workgroup < 16][tile start, loop begin, loop end, stores issued]
+__device__ unsigned long long g_v7_stamps[256 * 16 * 4];
+#define AV_STAMP7(SEQ, SLOT) do { if (threadIdx.x == 0 && blockIdx.x < 256 && (SEQ) < 16) g_v7_stamps[(blockIdx.x * 16 + (SEQ)) * 4 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define AV_STAMP(SLOT) do { } while (0)
+#define AV_STAMP7(SEQ, SLOT) do { } while (0)
 #endif
 
 // NWI wave-instructions per wave, each filling 8 tile rows x 128 B (lane -> row sub = lane>>3, physical chunk lane&7;
@@ -1305,8 +1309,11 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
     auto issue = [&](int tm0, int tn0, int t, int j, int sidx) {
         char* sl_ = smem + sidx * V4_HALF;
         const int k0 = t * BK;
-        if (j == 0) stage_rows<2>(A, p.lda, tm0, p.M, k0, sl_, w, lane);
-        else if (j == 2) stage_rows<2>(A, p.lda, tm0 + 128, p.M, k0, sl_, w, lane);
+        // rows of the 256-row window beyond this tile's bm_eff rows belong to the next row tile and get no MFMAs: their lanes re-read the
+        // tile's last row (one L1-resident line per instruction) instead of streaming 128 B each from L2
+        const int a_end = p.M - tm0 < bm_eff ? p.M : tm0 + bm_eff;
+        if (j == 0) stage_rows<2>(A, p.lda, tm0, a_end, k0, sl_, w, lane);
+        else if (j == 2) stage_rows<2>(A, p.lda, tm0 + 128, a_end, k0, sl_, w, lane);
         else if (j == 3) v7_stage_b(B, p.ldb, tn0, p.N, k0, sl_, w, lane, 0);
         else v7_stage_b(B, p.ldb, tn0, p.N, k0, sl_, w, lane, 1);
     };
@@ -1326,7 +1333,10 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
 
     const int sw = r & 7;
     const int ch0 = (g ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
-    const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
+    // m-tiles of a 128-row A half alternate between the two wavefront groups (group wr owns 16-row tiles wr, 2 + wr, 4 + wr, 6 + wr): a tile of
+    // bm_eff < 256 rows then takes its missing m-tiles evenly from both groups (the groups alternate on a SIMD and meet at every barrier, so
+    // the K-tile lasts as long as the group with MORE tiles: 208 rows = 7 + 6 tiles instead of 8 + 5)
+    const int a_row = (wr * 16 + r) * 128, b_row = (wc * 32 + r) * 128;
 
     int li = slot;
     int m0 = 0, n0 = 0, mb = 0;
@@ -1340,16 +1350,18 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         prefetch(m0, n0);
         load_bias(n0, bnext);
     }
+    int seq = 0;                                             // (diagnostic stamps only)
     while (li < cn) {
+        AV_STAMP7(seq, 0);
         const int nli = li + S;
         const bool has_next = nli < cn;
         int nm0 = 0, nn0 = 0, nmb = 0;
         if (has_next) coords(cs + nli, nm0, nn0, nmb);
         const int rows_here = p.M - m0 < bm_eff ? p.M - m0 : bm_eff;
-        auto ntiles = [&](int start) { int n = (rows_here - start + 15) >> 4; return n < 0 ? 0 : (n > 4 ? 4 : n); };
-        const int nmt0 = __builtin_amdgcn_readfirstlane(ntiles(wr * 64)), nmt1 = __builtin_amdgcn_readfirstlane(ntiles(128 + wr * 64));
+        auto ntiles = [&](int start) { int n = (rows_here - start + 31) >> 5; return n < 0 ? 0 : (n > 4 ? 4 : n); };       // my tiles start at rows start + 32 i
+        const int nmt0 = __builtin_amdgcn_readfirstlane(ntiles(wr * 16)), nmt1 = __builtin_amdgcn_readfirstlane(ntiles(128 + wr * 16));
 
-        f32x4 acc[2][2][4][2];                               // [A half][B half][m-tile][n-tile]; lane (g, r): row r of the m-tile, n-tile columns 4 g + e
+        f32x4 acc[2][2][4][2];                               // [A half][B half][m-tile 2 i + wr][n-tile]; lane (g, r): row r of the m-tile, n-tile columns 4 g + e
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1371,12 +1383,13 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (wr == 1) __builtin_amdgcn_s_barrier();           // wavefronts 4-7 run one barrier behind
+        AV_STAMP7(seq, 1);
 
         bf16x8 fa[4][2], fb[2][2];
 #define V7_READ_A(SLOT, NMT)                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < (NMT)) {                                                 \
-        fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch0);                           \
-        fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch1); }
+        fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 4096 + ch0);                           \
+        fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 4096 + ch1); }
 #define V7_READ_B(SLOT)                                                                                            \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
         fb[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                           \
@@ -1427,6 +1440,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
 #undef V7_MMA
         if (wr == 0) __builtin_amdgcn_s_barrier();           // balance the entry barrier of wavefronts 4-7: every fragment read of this tile has completed
         asm volatile("" ::: "memory");
+        AV_STAMP7(seq, 2);
 
         // the ring is free: request the next tile's first two K-tiles, then store this tile from the registers
         if (has_next) { prefetch(nm0, nn0); load_bias(nn0, bnext); }
@@ -1443,7 +1457,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
                 const int a = qd >> 1, b = qd & 1;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    v7_chunk<VO>(p, fl, acc[0][0][i][0], acc[0][0][i][1], bv, m0 + a * 128 + wr * 64 + i * 16 + r, n0 + wc * 64 + b * 32 + g * 8, m_end, cbase, R);
+                    v7_chunk<VO>(p, fl, acc[0][0][i][0], acc[0][0][i][1], bv, m0 + a * 128 + (2 * i + wr) * 16 + r, n0 + wc * 64 + b * 32 + g * 8, m_end, cbase, R);
                 if (qd == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -1464,6 +1478,8 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
                 for (int e = 0; e < 8; ++e) { const float t = bv[e]; bv[e] = bo[e]; bo[e] = t; }
             }
         }
+        AV_STAMP7(seq, 3);
+        ++seq;
         li = nli; m0 = nm0; n0 = nn0; mb = nmb;
     }
 
@@ -1883,6 +1899,11 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
 #ifdef AV_GEMM_STAMPS
 extern "C" int av_gemm_stamps_read(unsigned long long* host_out, int n_blocks) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int av_gemm_stamps7_read(unsigned long long* host_out, int clear) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_v7_stamps), sizeof(unsigned long long) * 256 * 16 * 4) != hipSuccess) return 1;
+    if (clear) { static unsigned long long z[256 * 16 * 4]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_v7_stamps), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
 }
 #endif
 
