@@ -1833,11 +1833,13 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
                 int dev = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
             }
+            static const int v7_g = [] { const char* e = getenv("AVAMD_GEMM_V7_G"); return e ? atoi(e) : 0; }();     // diagnostic: persistent workgroups per launch (0 = one per CU)
+            const int ng = v7_g > 0 && v7_g < ncu ? v7_g : ncu;
             const int nbM = av_cdiv(p.M, best_bm);
             const int ntile = nbM * nbN4;
             int nfull = ntile;
-            if (p.batch == 1 && v4_tail && ntile > ncu) { const int r = ntile % ncu; if (r > 0 && r <= ncu / 2) nfull = ntile - r; }
-            const int G = ntile < ncu ? ntile : ncu;
+            if (p.batch == 1 && v4_tail && ntile > ng) { const int r = ntile % ng; if (r > 0 && r <= ng / 2) nfull = ntile - r; }
+            const int G = ntile < ng ? ntile : ng;
             int rc = AV_OK;
             auto go = [&](auto kern) {
                 static bool attr = false;                    // one flag per instantiation (the lambda's call operator is a template)

@@ -117,10 +117,20 @@ class AvAdam(torch.optim.Optimizer):
         self._steps_seeded = False
         self._keep = None
 
+    def state_dict(self):
+        """torch.optim.Adam's format.  Under loss scaling only the device table knows the per-parameter step counts (overflowing steps are
+        skipped on the device): bring the host entries up to date first, so that a checkpoint taken through this method - not only through
+        ``checkpoint_dict`` - resumes with the right bias corrections."""
+        self.sync_steps()
+        return super().state_dict()
+
     def add_param_group(self, param_group):
+        if getattr(self, "_steps_dev", None) is not None:
+            self.sync_steps()                                       # the device table is rebuilt below: seed it from CURRENT counts
         super().add_param_group(param_group)
         self._slot = None
         self._steps_dev = None
+        self._steps_seeded = False
         self._plans = {}
 
     def _plan(self, plist, dev) -> _Plan:
