@@ -573,6 +573,7 @@ static bool lstm_split_enabled() {
 }
 // row groups that can be co-resident: every workgroup of the launch spins on its peers, so the whole grid (64 x row groups) must fit
 // on the device at two workgroups per CU (a partitioned GPU exposes fewer CUs)
+static int lstm_prepare(void);
 static int lstm_row_groups(int B) {
     static int ncu = 0;
     if (!ncu) {
@@ -583,9 +584,21 @@ static int lstm_row_groups(int B) {
     // up to 8 row groups = 512 workgroups, two per CU (forward 36 KB, backward 71 KB of LDS each): at B = 128 (both speakers in one call) every
     // workgroup then has ONE 16-row tile per step instead of two in sequence.  AVAMD_LSTM_NRG caps it (4 = the round-2 geometry).
     static const int cap = [] { const char* e = getenv("AVAMD_LSTM_NRG"); const int v = e ? atoi(e) : MAXRG; return v < 1 ? 1 : (v > MAXRG ? MAXRG : v); }();
+    // more than 4 row groups need TWO co-resident workgroups per CU: ask the runtime once what the split kernels' registers and LDS really
+    // admit on this device / partition (the count alone was an inference); fewer than two -> the round-2 geometry (one per CU)
+    static int per_cu = 0;
+    if (!per_cu) {
+        int f = 0, b = 0;
+        if (lstm_prepare() != AV_OK ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, (const void*)lstm_fwd_split, 256, LDS_FS) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)lstm_bwd_split, 256, LDS_BS) != hipSuccess) { f = b = 1; (void)hipGetLastError(); }
+        per_cu = f < b ? f : b;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 2) per_cu = 2;
+    }
     int nrg = ntile < cap ? ntile : cap;
-    while (nrg > 1 && 2 * NJT * nrg > 2 * ncu) --nrg;
-    return 2 * NJT * nrg <= 2 * ncu ? nrg : 0;
+    while (nrg > 1 && 2 * NJT * nrg > per_cu * ncu) --nrg;
+    return 2 * NJT * nrg <= per_cu * ncu ? nrg : 0;
 }
 
 static int lstm_prepare(void) {

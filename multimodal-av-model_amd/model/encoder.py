@@ -313,6 +313,9 @@ class VisualEncoder(nn.Module):
                         sd, bd = self._bn(blk.downsample[1], std, nbd, Md, training)
                         h = self._act(c2, s2, b2, slope, res=cd, rscale=sd, rshift=bd)
                     else:
+                        # the residual is added row by row: h must already be in the layer's (position-major) order.  True for ResNet-18, where the
+                        # first block of layer2 has a downsample branch; any other trunk would silently add permuted rows
+                        assert pm_in == pm_out, "position-major trunk: an identity residual needs its input in the layer's pixel order"
                         h = self._act(c2, s2, b2, slope, res=h)
                     Hc, Wc, Cc = H1, W1, blk.conv1.out_channels
                     pm_in = 1

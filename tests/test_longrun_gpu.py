@@ -95,10 +95,22 @@ def test_grad_scaler_with_gradientless_parameters_matches_torch_amp():
             if it in overflow:
                 assert torch.equal(pa.detach(), b)
             torch.testing.assert_close(pa.detach(), pr.detach(), rtol=2e-6, atol=2e-7)
-    o_av.sync_steps(s_av)
+    # a plain state_dict() (not only checkpoint_dict) must carry the DEVICE-side counts: under a scaler the host entries never move
+    sd = o_av.state_dict()
+    want = [int(o_ref.state[pr]["step"]) for pr in p_ref]
+    assert [int(sd["state"][i]["step"]) for i in range(len(p_av))] == want and want != [0] * len(want)
     for pr, pa in zip(p_ref, p_av):
         assert int(o_ref.state[pr]["step"]) == o_av.state[pa]["step"]
     assert s_av.steps_taken() == 8 and o_av.fused_launches == 10
+    # adding a parameter group rebuilds the device table: it must be re-seeded from the current counts, not from stale host values
+    extra = torch.randn(17, device="cuda").requires_grad_(True)
+    o_av.add_param_group({"params": [extra], "lr": 1e-3})
+    for pa in p_av:
+        pa.grad = torch.randn(pa.shape, device="cuda") * s_av.get_scale()
+    extra.grad = torch.randn(17, device="cuda") * s_av.get_scale()
+    s_av.step(o_av); s_av.update()
+    o_av.sync_steps(s_av)
+    assert [o_av.state[pa]["step"] for pa in p_av] == [w + 1 for w in want] and o_av.state[extra]["step"] == 1
 
 
 def _run_steps(t, batch, n, check_every=1):
