@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json metric: batch 64)")
     ap.add_argument("--seconds", type=float, default=4.0)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"], help="fp16 = the reference's GPU arithmetic (half MFMA operands, libavhip_f16.so); use with --loss-scaling")
     ap.add_argument("--variant", default="as_executed", choices=["as_executed", "deterministic"],
                     help="headline variant.  as_executed: two audio passes with HF-default dropout / LayerDrop / SpecAugment, what the reference's "
                          "train_epoch runs (model/trainer.py:94-95); deterministic: every regulariser 0 (the parity configuration), where the "
@@ -366,7 +366,7 @@ def main():
         imp("model.w2v2").PASS_STREAMS = False                 # probe leg: one stream, so that the events bracket exactly one kernel
         t.train_step(batch)
         torch.cuda.synchronize()
-        ops.GemmProbe.start(L.AV_BF16 if args.precision == "bf16" else L.AV_F32, L.A_ROWMAJOR, L.B_NK, True)
+        ops.GemmProbe.start(L.AV_BF16 if args.precision != "fp32" else L.AV_F32, L.A_ROWMAJOR, L.B_NK, True)
         ops.AttnProbe.start()
         probe_steps = min(3, args.steps)
         for _ in range(probe_steps):
@@ -405,7 +405,7 @@ def main():
                 out["loss_scaling"] = {"law": "torch.amp.GradScaler (init 65536, x2 / 2000 clean steps, x0.5 on overflow, overflowing steps skipped)",
                                        "final_scale": leg["scale"][0], "optimizer_steps_taken": leg["scale"][1]}
             return out
-        peak = 2500.0 if args.precision == "bf16" else 157.3
+        peak = 2500.0 if args.precision != "fp32" else 157.3
         head = line(head_leg)
         roof = None
         if probe and probe["records"]:
@@ -415,7 +415,7 @@ def main():
             traffic = tsrc = None
             for cand in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):       # separate rocprofv3 --pmc passes (see file)
                 pmc = os.path.join(ROOT, "profiles", cand)
-                if args.precision == "bf16" and os.path.exists(pmc):
+                if args.precision != "fp32" and os.path.exists(pmc):
                     tb = tl = 0                                                         # launch-weighted over the tilings of the family
                     for kname, kv in json.load(open(pmc))["kernels"].items():
                         if "gemm_nt_bf16_kernel<128, false, false, false>" in kname or "gemm_nt_bf16_v2_kernel" in kname or "gemm_nt_bf16_v4_kernel<false>" in kname or "gemm_nt_bf16_v7_kernel" in kname:
@@ -424,7 +424,7 @@ def main():
                     break
             n = len(probe["records"])
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_v7_kernel (256x256x64 8-phase, persistent, register-direct epilogue; v4 = its one-tile-per-workgroup form for the classes v7 does not specialise) + the 128x128 / 256x128 tilings of the same family: row-major NT products = every nn.Linear forward, dX through cached W^T, strided conv1d" if args.precision == "bf16" else "gemm_kernel<float,128,0,0>"),
+            roof = {"bound": "mfma", "kernel": ("gemm_nt_bf16_v7_kernel (256x256x64 8-phase, persistent, register-direct epilogue; v4 = its one-tile-per-workgroup form for the classes v7 does not specialise) + the 128x128 / 256x128 tilings of the same family: row-major NT products = every nn.Linear forward, dX through cached W^T, strided conv1d" if args.precision != "fp32" else "gemm_kernel<float,128,0,0>"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_note": f"HBM-side bytes per launch from profiles/{tsrc} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                     "algorithmic_bytes_per_launch": round(tot_by / n),

@@ -110,28 +110,37 @@ SIGNATURES = {
 }
 _RESTYPES = {"av_last_error": C.c_char_p}
 
-_lib = None
+_libs = {}
+
+
+def _path() -> str:
+    from . import precision
+    if precision.get_precision() == "fp16":
+        return os.environ.get("AVAMD_LIB_F16") or os.path.join(_HERE, "libavhip_f16.so")
+    return LIB_PATH
 
 
 def lib() -> C.CDLL:
-    """Load (once) and return the HIP library; raise if it is missing — no fallback exists."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    """Load (once per library) and return the HIP library of the current precision mode (fp32 / bf16: libavhip.so, fp16: libavhip_f16.so);
+    raise if it is missing - no fallback exists."""
+    path = _path()
+    l = _libs.get(path)
+    if l is None:
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python {os.path.join(_HERE, 'build.py')}` "
+                f"{path} is missing: build it with `python {os.path.join(_HERE, 'build.py')}` "
                 "(hipcc --offload-arch=gfx950). The MI355X path has no CPU/PyTorch fallback.")
         # torch first: libavhip.so links against libamdhip64, and the process must end up with ONE HIP runtime - the one PyTorch-ROCm
         # ships.  Loading this library before torch binds it to the system runtime instead; torch then shares that copy and kernels
         # registered here fail later in odd ways (hipFuncSetAttribute: "cannot raise dynamic LDS" in build() + smoke() of one process).
         import torch  # noqa: F401
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)           # AttributeError if a declared symbol is not exported
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, C.c_int)
-        _lib = l
-    return _lib
+        _libs[path] = l
+    return l
 
 
 def check(status: int, what: str = "") -> None:

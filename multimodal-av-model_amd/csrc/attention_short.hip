@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x8 row_frag(const bf16_t* img, int row, int ch) {
 __device__ __forceinline__ bf16x4 tr_read(const bf16_t* img, int r0, int n, int lane) {
     const int row = r0 + 4 * (lane >> 4) + ((lane >> 2) & 3), pp = lane & 3;
     const bf16_t* a = img + row * 64 + (((2 * n + (pp >> 1)) ^ (row & 7)) << 3) + 4 * (pp & 1);
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)a);
+    return AV_DS_READ_TR16_B64((lds_b4_t)a);
 }
 // A fragment [16 columns of the image][k = 32 rows r0 .. r0+31] in the k-slot order of pack8()
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int r0, int n, int lane) {
@@ -54,7 +54,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
     return v;
 }
 __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    return AV_MFMA_F32_16X16X32_LP(a, b, c, 0, 0, 0);
 }
 
 // rows [0, nvalid) of src (row stride rs elements, 64 contiguous) -> swizzled image of npad rows, zero-filled beyond nvalid

@@ -57,7 +57,7 @@ __device__ __forceinline__ void mma_rows<bf16_t>(f32x4& acc, const bf16_t* a, in
     for (int k0 = 0; k0 < K; k0 += 32) {
         const bf16x8 av = *(const bf16x8*)(a + r * lda + k0 + 8 * g);
         const bf16x8 bv = *(const bf16x8*)(b + r * ldb + k0 + 8 * g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+        acc = AV_MFMA_F32_16X16X32_LP(av, bv, acc, 0, 0, 0);
     }
 }
 template <>
@@ -85,7 +85,7 @@ template <int K> struct AFrag<bf16_t, K> {
 #pragma unroll
         for (int i = 0; i < K / 32; ++i) {
             const bf16x8 bv = *(const bf16x8*)(b + r * ldb + i * 32 + 8 * g);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[i], bv, acc, 0, 0, 0);
+            acc = AV_MFMA_F32_16X16X32_LP(f[i], bv, acc, 0, 0, 0);
         }
     }
 };

@@ -6,10 +6,29 @@
 
 #include "../../include/av_hip.h"
 
+// The 16-bit operand type of every kernel.  Default build (libavhip.so): bfloat16.  -DAV_HALF=1 builds the SAME sources with IEEE half
+// operands (libavhip_f16.so: the reference's GPU arithmetic, torch.cuda.amp fp16 autocast, model/trainer.py:9,40,65 - BASELINE configs[4]
+// "fp16 + fp32 master"): v_mfma_f32_16x16x32_f16 runs at the bf16 rate, accumulation stays fp32, and the dtype code AV_BF16 of the C-ABI means
+// "this library's 16-bit type".  The name bf16_t is kept for both.
+#ifdef AV_HALF
+typedef _Float16 bf16_t;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+#define AV_MFMA_F32_16X16X32_LP(A, B, C_, X, Y, Z) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C_, X, Y, Z)
+typedef __fp16 av_gcc_half4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ bf16x4 av_ds_read_tr16_b64_f16(__attribute__((address_space(3))) bf16x4* p) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) av_gcc_half4*)p));
+}
+#define AV_DS_READ_TR16_B64(P) av_ds_read_tr16_b64_f16(P)
+#else
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define AV_MFMA_F32_16X16X32_LP(A, B, C_, X, Y, Z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C_, X, Y, Z)
+#define AV_DS_READ_TR16_B64(P) __builtin_amdgcn_ds_read_tr16_b64_v4bf16(P)
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const CP p) {
             if (!(((vm[i] >> ky_) & 1u) && ((vm[i] >> (3 + kx_)) & 1u))) PF[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};          \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j], PF[i], acc[j][i], 0, 0, 0);                   \
+                acc[j][i] = AV_MFMA_F32_16X16X32_LP(WF[j], PF[i], acc[j][i], 0, 0, 0);                   \
     }
         C64_LOAD(wfA, pfA, 0)
 #pragma unroll

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_front_kernel(const FrontP p) {
                 uint4 av = make_uint4(ap[0], ap[1], ap[2], ap[3]);
                 const bf16x8 a = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = AV_MFMA_F32_16X16X32_LP(a, b[j], acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();                                        // all patch reads done: the image may overwrite it

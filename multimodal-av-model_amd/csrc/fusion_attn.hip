@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd_kernel(const FxP p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[0][i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[0][i][j] = AV_MFMA_F32_16X16X32_LP(fw[i], fa[j], acc[0][i][j], 0, 0, 0);
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd_kernel(const FxP p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[i], fv[j], acc[1][i][j], 0, 0, 0);
-                    acc[2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fvw[i], fv[j], acc[2][i][j], 0, 0, 0);
+                    acc[1][i][j] = AV_MFMA_F32_16X16X32_LP(fk[i], fv[j], acc[1][i][j], 0, 0, 0);
+                    acc[2][i][j] = AV_MFMA_F32_16X16X32_LP(fvw[i], fv[j], acc[2][i][j], 0, 0, 0);
                 }
         }
     }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd_kernel(const FxP p) {
             f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + IMG_K + krow * 256 + (((4 * ks + g) ^ sw256(krow)) << 4)), qf[ks], s4, 0, 0, 0);
+                s4 = AV_MFMA_F32_16X16X32_LP(*(const bf16x8*)(smem + IMG_K + krow * 256 + (((4 * ks + g) ^ sw256(krow)) << 4)), qf[ks], s4, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 s4[e] = (16 * t + 4 * g + e) < p.T ? s4[e] * c : -INFINITY;
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd_kernel(const FxP p) {
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
                 const int ch = 2 * n + (pp >> 1);
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(smem + IMG_V + row_lo * 256 + ((ch ^ sw256(row_lo)) << 4) + 8 * (pp & 1)));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(smem + IMG_V + row_hi * 256 + ((ch ^ sw256(row_hi)) << 4) + 8 * (pp & 1)));
-                O[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), pf, O[n], 0, 0, 0);
+                const bf16x4 lo = AV_DS_READ_TR16_B64((lds_b4_t)(smem + IMG_V + row_lo * 256 + ((ch ^ sw256(row_lo)) << 4) + 8 * (pp & 1)));
+                const bf16x4 hi = AV_DS_READ_TR16_B64((lds_b4_t)(smem + IMG_V + row_hi * 256 + ((ch ^ sw256(row_hi)) << 4) + 8 * (pp & 1)));
+                O[n] = AV_MFMA_F32_16X16X32_LP(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), pf, O[n], 0, 0, 0);
             }
         }
         if (qrow < p.T) {
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd2_kernel(const FxP p) {
                 if (j + 1 < 7) nxt = *(const bf16x8*)(st + x_off + (j + 1) * 2048 + choff);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], cur, acc[0][i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) acc[0][i][j] = AV_MFMA_F32_16X16X32_LP(fw[i], cur, acc[0][i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
             }
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd2_kernel(const FxP p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[i], cur, acc[1][i][j], 0, 0, 0);
-                    acc[2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fvw[i], cur, acc[2][i][j], 0, 0, 0);
+                    acc[1][i][j] = AV_MFMA_F32_16X16X32_LP(fk[i], cur, acc[1][i][j], 0, 0, 0);
+                    acc[2][i][j] = AV_MFMA_F32_16X16X32_LP(fvw[i], cur, acc[2][i][j], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd2_kernel(const FxP p) {
             for (int u = 0; u < 2; ++u) {
                 f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[u][ks], s4, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) s4 = AV_MFMA_F32_16X16X32_LP(kf[ks], qf[u][ks], s4, 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s4[e] = (16 * t + 4 * g + e) < p.T ? s4[e] * c : -INFINITY;
@@ -546,11 +546,11 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_fwd2_kernel(const FxP p) {
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
                 const int ch = 2 * n + (pp >> 1);
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(imgV + row_lo * 256 + ((ch ^ sw256(row_lo)) << 4) + 8 * (pp & 1)));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(imgV + row_hi * 256 + ((ch ^ sw256(row_hi)) << 4) + 8 * (pp & 1)));
+                const bf16x4 lo = AV_DS_READ_TR16_B64((lds_b4_t)(imgV + row_lo * 256 + ((ch ^ sw256(row_lo)) << 4) + 8 * (pp & 1)));
+                const bf16x4 hi = AV_DS_READ_TR16_B64((lds_b4_t)(imgV + row_hi * 256 + ((ch ^ sw256(row_hi)) << 4) + 8 * (pp & 1)));
                 const bf16x8 vt = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                O[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf[0], O[0][n], 0, 0, 0);
-                O[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf[1], O[1][n], 0, 0, 0);
+                O[0][n] = AV_MFMA_F32_16X16X32_LP(vt, pf[0], O[0][n], 0, 0, 0);
+                O[1][n] = AV_MFMA_F32_16X16X32_LP(vt, pf[1], O[1][n], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -615,8 +615,8 @@ __device__ __forceinline__ bf16x8 img_row(const char* img, int row, int ks, int 
 // A fragment [16 d = d-tile n][k = 32 rows r0 .. r0 + 31] of the transposed image, k-slot order of pack8 (rows r0 + 4 g + j, r0 + 16 + 4 g + j)
 __device__ __forceinline__ bf16x8 img_tr(const char* img, int r0, int n, int lane) {
     const int row_lo = r0 + 4 * (lane >> 4) + ((lane >> 2) & 3), row_hi = row_lo + 16, pp = lane & 3, ch = 2 * n + (pp >> 1);
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(img + row_lo * 256 + ((ch ^ sw256(row_lo)) << 4) + 8 * (pp & 1)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(img + row_hi * 256 + ((ch ^ sw256(row_hi)) << 4) + 8 * (pp & 1)));
+    const bf16x4 lo = AV_DS_READ_TR16_B64((lds_b4_t)(img + row_lo * 256 + ((ch ^ sw256(row_lo)) << 4) + 8 * (pp & 1)));
+    const bf16x4 hi = AV_DS_READ_TR16_B64((lds_b4_t)(img + row_hi * 256 + ((ch ^ sw256(row_hi)) << 4) + 8 * (pp & 1)));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 __device__ __forceinline__ bf16x8 pack8f(const f32x4& a, const f32x4& b) {
@@ -679,8 +679,8 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_bwd_kernel(const FxB p) {
                     f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-                        s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Qs, q0 + r, ks, g), kf[ks], s4, 0, 0, 0);     // S[query 4g+e][key r]
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Ds, q0 + r, ks, g), vf[ks], dp, 0, 0, 0);
+                        s4 = AV_MFMA_F32_16X16X32_LP(img_row(Qs, q0 + r, ks, g), kf[ks], s4, 0, 0, 0);     // S[query 4g+e][key r]
+                        dp = AV_MFMA_F32_16X16X32_LP(img_row(Ds, q0 + r, ks, g), vf[ks], dp, 0, 0, 0);
                     }
                     const f32x4 l4 = *(const f32x4*)(lse_s + q0 + 4 * g), d4 = *(const f32x4*)(del_s + q0 + 4 * g);
 #pragma unroll
@@ -693,8 +693,8 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_bwd_kernel(const FxB p) {
                 const bf16x8 pf = pack8f(Pt[0], Pt[1]), sf = pack8f(St[0], St[1]);
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
-                    dVt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr(Ds, 32 * qp, n, lane), pf, dVt[n], 0, 0, 0);   // dV^T[d][key]
-                    dKt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr(Qs, 32 * qp, n, lane), sf, dKt[n], 0, 0, 0);   // dK^T[d][key]
+                    dVt[n] = AV_MFMA_F32_16X16X32_LP(img_tr(Ds, 32 * qp, n, lane), pf, dVt[n], 0, 0, 0);   // dV^T[d][key]
+                    dKt[n] = AV_MFMA_F32_16X16X32_LP(img_tr(Qs, 32 * qp, n, lane), sf, dKt[n], 0, 0, 0);   // dK^T[d][key]
                 }
             }
             if (krow < T) {
@@ -728,8 +728,8 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_bwd_kernel(const FxB p) {
                     f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-                        s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Ks, k0 + r, ks, g), qf[ks], s4, 0, 0, 0);     // S^T[key 4g+e][query r]
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Vs, k0 + r, ks, g), df[ks], dp, 0, 0, 0);
+                        s4 = AV_MFMA_F32_16X16X32_LP(img_row(Ks, k0 + r, ks, g), qf[ks], s4, 0, 0, 0);     // S^T[key 4g+e][query r]
+                        dp = AV_MFMA_F32_16X16X32_LP(img_row(Vs, k0 + r, ks, g), df[ks], dp, 0, 0, 0);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(NT, 2) void fusion_xattn_bwd_kernel(const FxB p) {
                 }
                 const bf16x8 sf = pack8f(St[0], St[1]);
 #pragma unroll
-                for (int n = 0; n < 8; ++n) dQt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr(Ks, 32 * tp, n, lane), sf, dQt[n], 0, 0, 0);   // dQ^T[d][q]
+                for (int n = 0; n < 8; ++n) dQt[n] = AV_MFMA_F32_16X16X32_LP(img_tr(Ks, 32 * tp, n, lane), sf, dQt[n], 0, 0, 0);   // dQ^T[d][q]
             }
             if (qok) {
                 bf16_t* oq = p.dq + ((long long)b * T + qrow) * E + h * HD + 4 * g;

@@ -66,7 +66,7 @@ __device__ __forceinline__ void mma_step_bf16(const bf16_t* sa, const bf16_t* sb
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < WN_T; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = AV_MFMA_F32_16X16X32_LP(a[i], b[j], acc[i][j], 0, 0, 0);
 }
 
 template <int WN_T>

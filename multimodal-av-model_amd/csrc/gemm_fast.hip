@@ -92,8 +92,8 @@ __device__ __forceinline__ KmOff kmajor_off(int ct, int lane) {
     return o;
 }
 __device__ __forceinline__ bf16x8 kmajor_frag(const char* tile, const KmOff& o, int ks) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(tile + ks * 32 * 256 + o.lo));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(tile + ks * 32 * 256 + o.hi));
+    const bf16x4 lo = AV_DS_READ_TR16_B64((lds_b4_t)(tile + ks * 32 * 256 + o.lo));
+    const bf16x4 hi = AV_DS_READ_TR16_B64((lds_b4_t)(tile + ks * 32 * 256 + o.hi));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
             for (int i = 0; i < WM_T; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = AV_MFMA_F32_16X16X32_LP(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(V2_NT, 2) void gemm_nt_bf16_v2_kernel(const av_gemm
 #define MMAF(A_, B_)                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = AV_MFMA_F32_16X16X32_LP(A_[i], B_[j], acc[i][j], 0, 0, 0);
 
     if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -907,7 +907,7 @@ __device__ __forceinline__ void v4_quadrant_job(const av_gemm_args& p, const Fas
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                    acc[i][j] = AV_MFMA_F32_16X16X32_LP(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #ifdef AV_ABL_NOMFMA
 #define V4_MFMA_OP(ACC, A, B) asm volatile("" :: "v"(A), "v"(B))
 #else
-#define V4_MFMA_OP(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, ACC, 0, 0, 0)
+#define V4_MFMA_OP(ACC, A, B) ACC = AV_MFMA_F32_16X16X32_LP(A, B, ACC, 0, 0, 0)
 #endif
 #define V4_READ_A(SLOT, NMT)                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < (NMT)) {                                                 \
@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < ((QA) ? nmt1 : nmt0))                                \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-                acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0); \
+                acc[QA][QB][i][j] = AV_MFMA_F32_16X16X32_LP(fb[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                  \
@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(V6_NT, 1) void gemm_nt_bf16_v6_kernel(const av_gemm
 #define V6_A(ST, I, CH) (*(const bf16x8*)((ST) + a_off + (I) * 2048 + (CH)))
 #define V6_B(ST, J, CH) (*(const bf16x8*)((ST) + b_off + (J) * 2048 + (CH)))
 #define V6_MMA8(I, FA, FB)                                                                                         \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA, FB[j], acc[I][j], 0, 0, 0);
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[I][j] = AV_MFMA_F32_16X16X32_LP(FA, FB[j], acc[I][j], 0, 0, 0);
 
     bf16x8 fb[8], fbn[8], fa0, fa1, fa2;
     {

@@ -114,7 +114,7 @@ __device__ __forceinline__ typename GFrag<T>::type g_ld(const T* p, bool ok) {
     for (int i = 0; i < GFrag<T>::PER; ++i) z[i] = from_f32<T>(0.f);
     return ok ? *(const typename GFrag<T>::type*)p : z;
 }
-__device__ __forceinline__ void g_mma(f32x4& acc, const bf16x8& a, const bf16x8& b) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0); }
+__device__ __forceinline__ void g_mma(f32x4& acc, const bf16x8& a, const bf16x8& b) { acc = AV_MFMA_F32_16X16X32_LP(a, b, acc, 0, 0, 0); }
 __device__ __forceinline__ void g_mma(f32x4& acc, const f32x4& a, const f32x4& b) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b[jj], acc, 0, 0, 0);

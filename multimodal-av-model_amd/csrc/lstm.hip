@@ -33,7 +33,7 @@ __device__ __forceinline__ typename Frag<T>::type ld_frag(const T* p, bool ok) {
     return ok ? *(const typename Frag<T>::type*)p : z;
 }
 __device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    acc = AV_MFMA_F32_16X16X32_LP(a, b, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma(f32x4& acc, const f32x4& a, const f32x4& b) {
 #pragma unroll

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent(const PF p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const bf16x8 bq = *(const bf16x8*)(Wl + (q * 16 + r) * WLD + kk * 32 + 8 * g);
-                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc[q], 0, 0, 0);
+                        acc[q] = AV_MFMA_F32_16X16X32_LP(a, bq, acc[q], 0, 0, 0);
                     }
                 }
             }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent(const PB p) {
                         for (int kk = 0; kk < DCH / 32; ++kk) {
                             const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ (r & 15)) << 4));
                             const bf16x8 bq = *(const bf16x8*)(brow + kk * 32);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc, 0, 0, 0);
+                            acc = AV_MFMA_F32_16X16X32_LP(a, bq, acc, 0, 0, 0);
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this slot retired before iteration c+1 refills it
                     }
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void lstm_fwd_split(const PF p) {
                 for (int kk = 0; kk < 4; ++kk) {
                     const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ r) << 4));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[q][kk], acc[q], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) acc[q] = AV_MFMA_F32_16X16X32_LP(a, wf[q][kk], acc[q], 0, 0, 0);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_split(const PB p) {
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     const bf16x8 a = *(const bf16x8*)(arow + (((kk * 4 + g) ^ r) << 4));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wt[kk], acc, 0, 0, 0);
+                    acc = AV_MFMA_F32_16X16X32_LP(a, wt[kk], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) part[w * PSZ + pidx(4 * g + e, r)] = acc[e];

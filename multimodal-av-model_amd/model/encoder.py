@@ -78,7 +78,7 @@ class AudioEncoder(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------
 from .. import _lib as L          # noqa: E402
 from .. import ops                # noqa: E402
-from ..precision import compute_dtype  # noqa: E402
+from ..precision import compute_dtype, is_lp  # noqa: E402
 
 _TRUNK = ((64, 1), (128, 2), (256, 2), (512, 2))      # (planes, stride of the first block) for layer1..4
 
@@ -166,7 +166,7 @@ class VisualEncoder(nn.Module):
             with torch.no_grad():
                 w = torch.zeros((64, 36, 8), dtype=torch.float32, device=p.device)
                 w[:, :35, :7] = p.data.reshape(64, 35, 7)
-                hit = (ver, ops.cast(w.reshape(64, 288).contiguous(), torch.bfloat16))
+                hit = (ver, ops.cast(w.reshape(64, 288).contiguous(), compute_dtype()))
             self._wcache[key] = hit
         return hit[1]
 
@@ -174,7 +174,7 @@ class VisualEncoder(nn.Module):
         """Build (or refresh) every cached weight re-layout on the CURRENT stream.  The trainer runs the two lip streams on two HIP streams;
         called before they fork, so that the following stream never reads a re-layout the leading stream is still writing (first step)."""
         conv0 = self.frontend3D[0]
-        if dtype == torch.bfloat16 and tuple(conv0.kernel_size) == (5, 7, 7):
+        if is_lp(dtype) and tuple(conv0.kernel_size) == (5, 7, 7):
             self._w_front(conv0)
         self._w(conv0, dtype)
         for li in range(1, 5):
@@ -217,7 +217,7 @@ class VisualEncoder(nn.Module):
 
     def _c64_ok(self, conv: nn.Module, dtype, N, H, W, Cin) -> bool:
         k, st, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        return (dtype == torch.bfloat16 and (k, st, pad, Cin, conv.out_channels) == (3, 1, 1, 64, 64) and W <= 31
+        return (is_lp(dtype) and (k, st, pad, Cin, conv.out_channels) == (3, 1, 1, 64, 64) and W <= 31
                 and N * H * W < (1 << 24) and FAST_C64)
 
     def _conv2d(self, x, N, H, W, Cin, conv: nn.Module, dtype, training: bool, in_act=None, pm: int = 0):
@@ -270,7 +270,7 @@ class VisualEncoder(nn.Module):
         Ho, Wo = (H + 2 * conv0.padding[1] - kh) // conv0.stride[1] + 1, (W + 2 * conv0.padding[2] - kw) // conv0.stride[2] + 1
         M = B * T * Ho * Wo
         y = torch.empty((M, 64), dtype=dtype, device=dev)
-        fast = (dtype == torch.bfloat16 and (kt, kh, kw) == (5, 7, 7) and tuple(conv0.stride) == (1, 2, 2)
+        fast = (is_lp(dtype) and (kt, kh, kw) == (5, 7, 7) and tuple(conv0.stride) == (1, 2, 2)
                 and tuple(conv0.padding) == (2, 3, 3) and H % 16 == 0 and W % 32 == 0)
         if fast:    # patch-in-LDS implicit GEMM (frontend3d.hip); one BN partial per 8x16 output tile
             nblk = B * T * (Ho // 8) * (Wo // 16)
@@ -294,7 +294,7 @@ class VisualEncoder(nn.Module):
         Hc, Wc, Cc = Hp, Wp, 64
         # position-major order from layer2 on (bf16 fast path: input channels a multiple of 64, plain 3x3 / 1x1 filters)
         FB = 256                                                # frames per position-major block = the row tile of the 8-phase kernel
-        use_pm = POS_MAJOR and dtype == torch.bfloat16 and N % FB == 0
+        use_pm = POS_MAJOR and is_lp(dtype) and N % FB == 0
         pm_in = 0                                               # pixel order of h
         for li in range(1, 5):
             for blk in getattr(self.trunk, f"layer{li}"):

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops
-from ..precision import compute_dtype
+from ..precision import compute_dtype, is_lp
 from ..utils.shadow import ParamCache
 
 Tensor = torch.Tensor
@@ -52,7 +52,7 @@ def lstm_forward(mod: "CrossAttentionFusion", x_tm: Tensor, save: bool):
         if last:
             out_bt = torch.empty((B, T, 2 * H), dtype=dtype, device=dev)
         st = ops.stream()
-        if PERSISTENT_LSTM and dtype == torch.bfloat16 and H == 512:
+        if PERSISTENT_LSTM and is_lp(dtype) and H == 512:
             cnt = torch.empty(L.LSTM_COUNTER_INTS, dtype=torch.int32, device=dev)
             L.check(L.lib().av_lstm_fwd_layer(ops.ptr(gx), ops.ptr(whh), ops.ptr(hseq), ops.ptr(cseq), ops.ptr(gates),
                                               ops.ptr(out_bt) if last else None, ops.ptr(cnt), T, B, H, st), "av_lstm_fwd_layer")
@@ -86,7 +86,7 @@ def lstm_backward(mod: "CrossAttentionFusion", layers, dout_bt: Tensor, grads: D
         dgates = torch.empty((T, B, 2, 4 * H), dtype=dtype, device=dev)
         dc = torch.empty((2, B, H), dtype=torch.float32, device=dev)
         st = ops.stream()
-        if PERSISTENT_LSTM and dtype == torch.bfloat16 and H == 512:
+        if PERSISTENT_LSTM and is_lp(dtype) and H == 512:
             cnt = torch.empty(L.LSTM_COUNTER_INTS, dtype=torch.int32, device=dev)
             L.check(L.lib().av_lstm_bwd_layer(ops.ptr(dout), ops.dt(dout), do_bs, do_ts, ops.ptr(dgates), ops.ptr(whhT), ops.ptr(gates),
                                               ops.ptr(cseq), ops.ptr(dc), ops.ptr(cnt), T, B, H, st), "av_lstm_bwd_layer")
@@ -150,7 +150,7 @@ class _FusionFn(torch.autograd.Function):
         Win = c(mha.in_proj_weight)
         bin_ = mha.in_proj_bias.data
         scale = hd ** -0.5                                   # torch scales q by 1/sqrt(hd) (torch:functional.py:6578)
-        if FUSED_XATTN and dtype == torch.bfloat16 and E == 512 and nh == 4 and Tv <= 112:
+        if FUSED_XATTN and is_lp(dtype) and E == 512 and nh == 4 and Tv <= 112:
             o, q, kv, lse = ops.fusion_xattn_fwd(a, v, Win, bin_, nh, scale, save)
         else:
             q = ops.linear(a, Win[:E], bin_[:E].contiguous()).view(B, Tv, nh, hd)
@@ -200,7 +200,7 @@ class _FusionFn(torch.autograd.Function):
         g["cross_attn_audio.out_proj.bias"] = ops.colsum_into(da2v, A("xa.out_proj.bias", (E,), dev, True))
         do = ops.matmul_nn(da2v, c(mha.out_proj.weight)).view(B, Tv, nh, hd)
         q, kv = s["q"], s["kv"]
-        if FUSED_XATTN and dtype == torch.bfloat16 and E == 512 and nh == 4 and Tv <= 112:
+        if FUSED_XATTN and is_lp(dtype) and E == 512 and nh == 4 and Tv <= 112:
             dq, dkv = ops.fusion_xattn_bwd(q, kv, s["o"], do.contiguous(), s["lse"], hd ** -0.5)
         else:
             dq = torch.empty_like(q); dkv = torch.empty_like(kv)

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops
-from ..precision import compute_dtype
+from ..precision import compute_dtype, is_lp
 from ..utils import init as _init
 from ..utils.shadow import ParamCache
 
@@ -409,7 +409,7 @@ class Wav2Vec2ModelHIP(nn.Module):
             u = torch.empty((B, T, cfg["intermediate_size"]), dtype=dtype, device=dev) if keep_ctx else None
             # bf16: the saved tensor is the site's gradient factor gelu'(u) o mask / (1 - p) instead of u, so the dX product of the
             # backward ends in one multiply (no erf / exp / mask regeneration while its matrix pipe waits)
-            gf = FFN_GF and keep_ctx and dtype == torch.bfloat16
+            gf = FFN_GF and keep_ctx and is_lp(dtype)
             g = ops.linear(x2, self.c(p + "feed_forward.intermediate_dense.weight", dtype),
                            self.P(p + "feed_forward.intermediate_dense.bias").data, out_dtype=dtype, act=L.ACT_GELU_GF if gf else L.ACT_GELU, C2=u,
                            drop=(ac_p, seed, li * 8 + 1))
@@ -518,7 +518,7 @@ class Wav2Vec2ModelHIP(nn.Module):
         hd = Hd // nh
         nl = cfg["num_hidden_layers"]
         scale = hd ** -0.5
-        fuse_lp = dtype == torch.bfloat16
+        fuse_lp = is_lp(dtype)
         dh, dh_lp, dmid_c = st["dh"], st["dh_lp"], st["dmid"]
         if dmid_c is not None and 6 <= li + 1 <= 9 and li + 1 < nl:
             ops.axpby(0.25, dmid_c, 1.0, dh)

@@ -11,21 +11,27 @@ from typing import Optional
 import torch
 
 from . import _lib as L
+from . import precision
 from ._lib import AV_BF16, AV_F32
 
 Tensor = torch.Tensor
 
 
+def _lp() -> torch.dtype:
+    """The 16-bit operand type of the library in use: float16 in precision mode "fp16" (libavhip_f16.so), bfloat16 otherwise."""
+    return torch.float16 if precision.get_precision() == "fp16" else torch.bfloat16
+
+
 def dt(t: Tensor) -> int:
     if t.dtype == torch.float32:
         return AV_F32
-    if t.dtype == torch.bfloat16:
-        return AV_BF16
-    raise TypeError(f"unsupported dtype {t.dtype} (libavhip handles float32 / bfloat16)")
+    if t.dtype == _lp():
+        return AV_BF16                                              # dtype code 1 = "the library's 16-bit type"
+    raise TypeError(f"unsupported dtype {t.dtype} (the library of precision mode {precision.get_precision()!r} handles float32 / {_lp()})")
 
 
 def tdt(code: int) -> torch.dtype:
-    return torch.float32 if code == AV_F32 else torch.bfloat16
+    return torch.float32 if code == AV_F32 else _lp()
 
 
 def ptr(t: Optional[Tensor]):
@@ -202,7 +208,7 @@ def transpose_cached(b: Tensor, hot_ok: bool = False) -> Optional[Tensor]:
 
 
 def _fast_ok(t: Tensor, K: int, N: int) -> bool:
-    return t.dtype == torch.bfloat16 and K >= 64 and N > 64
+    return precision.is_lp(t.dtype) and K >= 64 and N > 64
 
 
 # k-major operands straight into the fast GEMM (transposed LDS reads) instead of a transpose pass; AVAMD_GEMM_KMAJOR=0 = old path
@@ -304,7 +310,7 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     rows = x.numel() // cols
     assert x.is_contiguous() and dy.is_contiguous()
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    dxl = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if lp_copy else None
+    dxl = torch.empty(x.shape, dtype=_lp(), device=x.device) if lp_copy else None
     nblk = max(1, min(512, (rows + 15) // 16))
     part = torch.empty((nblk, 2 * cols), dtype=torch.float32, device=x.device) if want_param_grads else None
     if lp_copy and lp_drop is not None and lp_drop[0] > 0:
@@ -410,7 +416,7 @@ _ATTN_SHORT = os.environ.get("AVAMD_ATTN_SHORT", "1") != "0"
 
 
 def attention_mask_shape_ok(dtype, B: int, Tq: int, Tk: int, D: int) -> bool:
-    return _ATTN_SHORT and dtype == torch.bfloat16 and D == 64 and Tq <= 256 and Tk <= 256 and B <= 65535
+    return _ATTN_SHORT and precision.is_lp(dtype) and D == 64 and Tq <= 256 and Tk <= 256 and B <= 65535
 
 
 def attention_dropmask(B: int, H: int, Tq: int, Tk: int, drop: tuple, device) -> Tensor:
@@ -481,7 +487,7 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, dq: Tensor, dk: T
     B, Tq, H, D = q.shape
     Tk = k.shape[1]
     dp, dseed, dstream = (float(drop[0]), int(drop[1]), int(drop[2])) if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
-    if q.dtype == torch.bfloat16 and o is not None and lse is not None:     # fused flash-style backward (attention_bwd.hip)
+    if precision.is_lp(q.dtype) and o is not None and lse is not None:     # fused flash-style backward (attention_bwd.hip)
         _chk_view(o, "o")
         st = (C.c_longlong * 16)(*[x for t in (q, k, v, o, do, dq, dk, dv) for x in (t.stride(0), t.stride(1))])
         delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)

@@ -12,6 +12,8 @@ import weakref
 from typing import Callable, List, Optional, Sequence
 
 import torch
+
+from ..precision import is_lp
 from torch import Tensor
 
 _SHADOW = {}          # id(parameter) -> (weakref to the parameter, flat bf16 view, entry); Tensor.__eq__ is elementwise, so no WeakKeyDictionary
@@ -50,7 +52,7 @@ class ParamCache:
                 val = fn()
             hit = _Entry(ver, val, params, dtype)
             self.d[key] = hit
-            if flat and dtype == torch.bfloat16 and val.is_contiguous() and val.numel() == sum(p.numel() for p in params):
+            if flat and is_lp(dtype) and val.is_contiguous() and val.numel() == sum(p.numel() for p in params):
                 base, off = val.view(-1), 0
                 for p in params:
                     pid = id(p)

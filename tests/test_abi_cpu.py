@@ -24,6 +24,22 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(L.SIGNATURES) == names, "ctypes table and header disagree"
 
 
+def test_half_library_exports_the_same_abi():
+    """libavhip_f16.so (the same sources built with IEEE-half operands, precision mode "fp16") carries the identical C-ABI."""
+    L = pkg("_lib"); P = pkg("precision")
+    old = P.get_precision()
+    P.set_precision("fp16")
+    try:
+        lib = L.lib()
+        assert lib is not None and lib._name.endswith("libavhip_f16.so")
+        for n in _declared():
+            assert hasattr(lib, n), f"{n} not exported by libavhip_f16.so"
+        assert lib.av_version() >= 1
+    finally:
+        P.set_precision(old)
+    assert L.lib()._name.endswith("libavhip.so")
+
+
 def test_errors_are_reported_not_aborted():
     L = pkg("_lib")
     lib = L.lib()
