@@ -1445,6 +1445,20 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         // the ring is free: request the next tile's first two K-tiles, then store this tile from the registers
         if (has_next) { prefetch(nm0, nn0); load_bias(nn0, bnext); }
         const int m_end = m0 + rows_here;
+        constexpr bool ROLL = ACT != AV_ACT_MUL_AUX;
+        if constexpr (!ROLL) {
+            // saved-factor multiply (the dX product above an FFN activation): all 16 chunks unrolled, so that the factor loads of later chunks are
+            // in flight while earlier chunks are stored - the rolled form below waits for a load round trip per quadrant (150 -> 136 us on
+            // 12736 x 4096 x 1024, = the plain product).  The fp32-residual classes did not gain from it (their epilogue moves 2 x 52 MB per
+            // round at the memory rate whatever the order) and stay rolled with the rest
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        v7_chunk<VO>(p, fl, acc[a][b][i][0], acc[a][b][i][1], bcur[b], m0 + a * 128 + (2 * i + wr) * 16 + r, n0 + wc * 64 + b * 32 + g * 8, m_end, cbase, R);
+        } else
         {
             // ONE copy of the epilogue body for four m-tiles (code size: it is inlined with every activation / dropout / residual branch).  The
             // quadrants (a, b) = (0,0) (0,1) (1,0) (1,1) pass through the registers of quadrant (0,0) - dead once stored - and the two bias
