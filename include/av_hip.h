@@ -229,6 +229,15 @@ int av_class_order(const long long* mask, long long n, long long* order, void* s
  * w bf16 [64][288] with k = (kt*7+ky)*8+kx (kx padded to 8, K padded to 288), y bf16 [B*T][H/2][W/2][64],
  * stats [B*T*(H/16)*(W/32)][2][64] BatchNorm partials (optional). */
 int av_conv3d_front(const float* x, const void* w, void* y, float* stats, int B, int T, int H, int W, void* stream);
+/* the same convolution fused with the first half of model/encoder.py:62-64 (BatchNorm3d + PReLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1))):
+ * instead of the conv output it writes, per 3 x 3 / stride 2 / pad 1 pooling window and channel, the MAXIMUM and the MINIMUM of the
+ * (bf16-rounded) conv output: ymax, ymin bf16 [B*T][H/4][W/4][64].  Train-mode BatchNorm needs the whole batch before it can be applied,
+ * but bn followed by prelu is monotone or V-shaped per channel, so max over the window of prelu(bn(x)) = max(prelu(bn(max x)), prelu(bn(min x)))
+ * exactly; av_bn_prelu_minmax evaluates that once scale / shift exist.  stats as above (partials of the UNPOOLED output). */
+int av_conv3d_front_pool(const float* x, const void* w, void* ymax, void* ymin, float* stats, int B, int T, int H, int W, void* stream);
+/* out[i] = max(prelu(ymax[i] * scale[c] + shift[c]), prelu(ymin[i] * scale[c] + shift[c])), c = i % 64; bf16, n elements (a multiple of 64) */
+int av_bn_prelu_minmax(const void* ymax, const void* ymin, const float* scale, const float* shift, const float* slope, void* out, long long n,
+                       void* stream);
 /* bf16 fast path of the 3x3 / stride 1 / pad 1, 64 -> 64 channel convolutions of ResNet-18 layer1 (model/encoder.py:44-57):
  * x bf16 NHWC [n_img][H][W][64], w bf16 [64][9*64] with k = (ky*3+kx)*64 + c, y bf16 [n_img*H*W][64],
  * stats [ceil(n_img*H*W/256)][2][64] BatchNorm partials (optional).  Weights stay in LDS, the input is staged once per filter row. */

@@ -79,6 +79,8 @@ SIGNATURES = {
     "av_scatter_rows": [vp, vp, vp, ll, i32, f32, i32, vp],
     "av_class_order": [vp, ll, vp, vp],
     "av_conv3d_front": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "av_conv3d_front_pool": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "av_bn_prelu_minmax": [vp, vp, vp, vp, vp, vp, ll, vp],
     "av_conv3x3_c64": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "av_bn_finalize": [vp, i32, ll, vp, vp, vp, vp, f32, f32, i32, vp, vp, i32, vp, i32, vp],
     "av_bn_act": [vp, vp, vp, vp, vp, vp, vp, vp, i32, ll, i32, vp],

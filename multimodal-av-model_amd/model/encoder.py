@@ -91,6 +91,9 @@ FUSE_MID_ACT = os.environ.get("AVAMD_FUSE_MID_ACT", "1") != "0"  # 0: separate B
 # K-tiles instead of multiplying zero lines - 11 % / 21 % / 40 % of the implicit-GEMM work of layer2 / layer3 / layer4.  BatchNorm, PReLU and
 # the residual adds are per-pixel, so they do not see the order; the average pool reads it.  0: frame-major everywhere (A/B runs)
 POS_MAJOR = os.environ.get("AVAMD_CONV_POSMAJOR", "1") != "0"
+# Front-end: Conv3d fused with the window max / min of its raw output (frontend3d.hip POOL form + av_bn_prelu_minmax): the 1.9 GB conv output of a
+# 64 x 100-frame batch is neither written nor read back; bit-identical to the unfused path.  0: conv -> HBM -> BN + PReLU + MaxPool pass (A/B runs)
+FRONT_POOL = os.environ.get("AVAMD_FRONT_POOL", "1") != "0"
 
 
 class BasicBlock(nn.Module):
@@ -269,15 +272,27 @@ class VisualEncoder(nn.Module):
         kt, kh, kw = conv0.kernel_size
         Ho, Wo = (H + 2 * conv0.padding[1] - kh) // conv0.stride[1] + 1, (W + 2 * conv0.padding[2] - kw) // conv0.stride[2] + 1
         M = B * T * Ho * Wo
-        y = torch.empty((M, 64), dtype=dtype, device=dev)
         fast = (is_lp(dtype) and (kt, kh, kw) == (5, 7, 7) and tuple(conv0.stride) == (1, 2, 2)
                 and tuple(conv0.padding) == (2, 3, 3) and H % 16 == 0 and W % 32 == 0)
-        if fast:    # patch-in-LDS implicit GEMM (frontend3d.hip); one BN partial per 8x16 output tile
+        N = B * T
+        Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        pooled = None
+        if fast and FRONT_POOL:
+            # conv + window max / min of the raw output in one kernel (frontend3d.hip, POOL form): the 4x larger conv output never reaches HBM;
+            # BatchNorm + PReLU + MaxPool (model/encoder.py:62-64) are finished from the two extremes once the batch statistics exist
+            nblk = B * T * (Ho // 8) * (Wo // 16)
+            stats = torch.empty((nblk, 2, 64), dtype=torch.float32, device=dev) if training else None
+            pooled = torch.empty((2, N * Hp * Wp, 64), dtype=dtype, device=dev)
+            L.check(L.lib().av_conv3d_front_pool(ops.ptr(x.contiguous().float()), ops.ptr(self._w_front(conv0)), ops.ptr(pooled[0]), ops.ptr(pooled[1]),
+                                                 ops.ptr(stats), B, T, H, W, ops.stream()), "av_conv3d_front_pool")
+        elif fast:    # patch-in-LDS implicit GEMM (frontend3d.hip); one BN partial per 8x16 output tile
+            y = torch.empty((M, 64), dtype=dtype, device=dev)
             nblk = B * T * (Ho // 8) * (Wo // 16)
             stats = torch.empty((nblk, 2, 64), dtype=torch.float32, device=dev) if training else None
             L.check(L.lib().av_conv3d_front(ops.ptr(x.contiguous().float()), ops.ptr(self._w_front(conv0)), ops.ptr(y), ops.ptr(stats),
                                             B, T, H, W, ops.stream()), "av_conv3d_front")
         else:
+            y = torch.empty((M, 64), dtype=dtype, device=dev)
             xin = ops.cast(x.contiguous().float().view(B, T, H, W), dtype)
             nblk = (M + 127) // 128
             stats = torch.empty((nblk, 2, 64), dtype=torch.float32, device=dev) if training else None
@@ -286,11 +301,13 @@ class VisualEncoder(nn.Module):
             ops.gemm(xin, self._w(conv0, dtype), y, M=M, N=64, K=kt * kh * kw, lda=0, ldb=kt * kh * kw, ldc=64, a_mode=L.A_CONV3D1,
                      conv=geo, stats=stats)
         sc, sh = self._bn(self.frontend3D[1], stats, nblk, M, training)
-        N = B * T
-        Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         h = torch.empty((N * Hp * Wp, 64), dtype=dtype, device=dev)
-        L.check(L.lib().av_bn_prelu_maxpool(ops.ptr(y), ops.ptr(sc), ops.ptr(sh), ops.ptr(self.frontend3D[2].weight.data), ops.ptr(h),
-                                            ops.dt(h), N, Ho, Wo, 64, ops.stream()), "av_bn_prelu_maxpool")
+        if pooled is not None:
+            L.check(L.lib().av_bn_prelu_minmax(ops.ptr(pooled[0]), ops.ptr(pooled[1]), ops.ptr(sc), ops.ptr(sh), ops.ptr(self.frontend3D[2].weight.data),
+                                               ops.ptr(h), h.numel(), ops.stream()), "av_bn_prelu_minmax")
+        else:
+            L.check(L.lib().av_bn_prelu_maxpool(ops.ptr(y), ops.ptr(sc), ops.ptr(sh), ops.ptr(self.frontend3D[2].weight.data), ops.ptr(h),
+                                                ops.dt(h), N, Ho, Wo, 64, ops.stream()), "av_bn_prelu_maxpool")
         Hc, Wc, Cc = Hp, Wp, 64
         # position-major order from layer2 on (bf16 fast path: input channels a multiple of 64, plain 3x3 / 1x1 filters)
         FB = 256                                                # frames per position-major block = the row tile of the 8-phase kernel

@@ -76,6 +76,38 @@ def test_visual_encoder_position_major_layers_equal_frame_major(training):
             assert float((stats[0][k] - stats[1][k]).abs().max()) <= 1e-3 * max(1.0, float(stats[0][k].abs().max())), k
 
 
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("slope_sign", [1.0, -1.0])
+def test_front_end_pooled_in_the_conv_kernel_equals_the_unfused_path(training, slope_sign):
+    """frontend3d.hip POOL form + av_bn_prelu_minmax (window max / min of the raw Conv3d output, BatchNorm + PReLU applied to the two extremes)
+    against Conv3d -> HBM -> av_bn_prelu_maxpool on the same input: bit-identical features and running statistics.  Negative BatchNorm scales
+    (gamma < 0) and negative PReLU slopes (V-shaped activation) are the cases where the MINIMUM decides; T = 7 frames exercises the temporal
+    padding, 96 x 96 frames three column strips (halo column) and six row tiles (carry row)."""
+    _p("bf16")
+    init = pkg("utils.init"); enc = pkg("model.encoder")
+    sd = _clone(init.visual_state_dict())
+    g = torch.Generator().manual_seed(23)
+    sd["frontend3D.1.weight"] = sd["frontend3D.1.weight"] * torch.where(torch.rand(64, generator=g) < 0.4, -1.0, 1.0)       # some negative BN scales
+    sd["frontend3D.2.weight"] = (sd["frontend3D.2.weight"].abs() + 0.1) * torch.where(torch.rand(64, generator=g) < 0.5, slope_sign, 1.0)
+    x = torch.rand(3, 1, 7, 96, 96, generator=g).cuda()
+    outs, stats = [], []
+    for fused in (False, True):
+        enc.FRONT_POOL = fused
+        try:
+            ve = enc.VisualEncoder().cuda(); ve.load_state_dict(sd)
+            for p in ve.parameters():
+                p.requires_grad = False
+            ve.train(training)
+            outs.append(ve(x).float().cpu())
+            stats.append({k: v.float().cpu() for k, v in ve.state_dict().items() if "running" in k})
+        finally:
+            enc.FRONT_POOL = True
+    assert outs[0].shape == (3, 7, 512) and bool(torch.isfinite(outs[0]).all())
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    for k in stats[0]:
+        assert torch.equal(stats[0][k], stats[1][k]), k
+
+
 @pytest.mark.parametrize("precision,tol,gtol", [("fp32", 1e-3, 2e-3), ("bf16", 6e-2, 0.1)])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_fusion_fwd_bwd(precision, tol, gtol, ragged):
