@@ -1090,8 +1090,11 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #else
 #define V4_MFMA_OP(ACC, A, B) ACC = AV_MFMA_F32_16X16X32_LP(A, B, ACC, 0, 0, 0)
 #endif
+// (no per-m-tile skipping of short tiles: an `if (i < nmt)` inside these unrolled loops compiles to a scalar branch around every pair of MFMAs /
+// fragment reads - a dozen taken branches inside a 16-MFMA cluster cost more than the MFMAs they save; rows past a tile's bm_eff rows are
+// clamped re-reads of its last row, computed and never stored)
 #define V4_READ_A(SLOT, NMT)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < (NMT)) {                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
         fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch0);                           \
         fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch1); }
 #define V4_READ_B(SLOT)                                                                                            \
@@ -1104,7 +1107,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < ((QA) ? nmt1 : nmt0))                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
                 V4_MFMA_OP(acc[QA][QB][i][j], fa[i][ks], fb[j][ks]);                                               \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
@@ -1321,14 +1324,11 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         issue(tm0, tn0, 0, 0, 0); issue(tm0, tn0, 0, 1, 1); issue(tm0, tn0, 0, 2, 2); issue(tm0, tn0, 0, 3, 3);
         if (nk > 1) { issue(tm0, tn0, 1, 0, 4); issue(tm0, tn0, 1, 1, 5); issue(tm0, tn0, 1, 2, 6); issue(tm0, tn0, 1, 3, 7); }
     };
-    // bias of my 16 columns of a tile: [b][8]
-    auto load_bias = [&](int tn0, float (&bb)[2][8]) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int gn = tn0 + wc * 64 + b * 32 + g * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bb[b][e] = (bias && gn + e < p.N) ? bias[gn + e] : 0.f;
-        }
+    // bias of the 64 columns of my wavefront: lane l holds column wc 64 + l (ONE register across the main loop; the epilogue fetches the 16
+    // values a lane needs - columns b 32 + g 8 + e - from their lanes by ds_bpermute)
+    auto load_bias = [&](int tn0) -> float {
+        const int gn = tn0 + wc * 64 + lane;
+        return (bias && gn < p.N) ? bias[gn] : 0.f;
     };
 
     const int sw = r & 7;
@@ -1340,15 +1340,11 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
 
     int li = slot;
     int m0 = 0, n0 = 0, mb = 0;
-    float bnext[2][8];                                       // bias of the tile whose ring prefetch is in flight (loop-carried)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bnext[b][e] = 0.f;
-    if (li < cn) {
+    float bnext = 0.f;                                       // bias (my lane's column) of the tile whose ring prefetch is in flight (loop-carried)
+        if (li < cn) {
         coords(cs + li, m0, n0, mb);
         prefetch(m0, n0);
-        load_bias(n0, bnext);
+        bnext = load_bias(n0);
     }
     int seq = 0;                                             // (diagnostic stamps only)
     while (li < cn) {
@@ -1375,34 +1371,51 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the bias loads of this tile were issued with its prefetch: consume them HERE (the compiler's wait for them lands beside the wait
         // above, not in the epilogue behind the next tile's just-issued LDS-DMA)
-        float bcur[2][8];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { asm volatile("" : "+v"(bnext[b][e])); bcur[b][e] = bnext[b][e]; }
+        asm volatile("" : "+v"(bnext));
+        const float bcur = bnext;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (wr == 1) __builtin_amdgcn_s_barrier();           // wavefronts 4-7 run one barrier behind
         AV_STAMP7(seq, 1);
 
         bf16x8 fa[4][2], fb[2][2];
-#define V7_READ_A(SLOT, NMT)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < (NMT)) {                                                 \
+// The count of live m-tiles (nmt0 / nmt1: rows of a short tile) is wave-uniform: ONE scalar branch per read group / MFMA cluster selects a
+// straight-line body for that count.  A per-tile `if (i < nmt)` inside the unrolled loops compiles to a scalar branch around EVERY pair of
+// MFMAs and every pair of fragment reads - a dozen taken branches inside a 16-MFMA cluster that is meant to issue back to back.
+#define V7_READ_A_N(SLOT, N)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < (N); ++i) {                                                              \
         fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 4096 + ch0);                           \
         fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 4096 + ch1); }
+#ifdef AV_V7_SKIP
+#define V7_READ_A(SLOT, NMT)                                                                                       \
+    if ((NMT) == 4) { V7_READ_A_N(SLOT, 4) } else if ((NMT) == 3) { V7_READ_A_N(SLOT, 3) }                         \
+    else if ((NMT) == 2) { V7_READ_A_N(SLOT, 2) } else if ((NMT) == 1) { V7_READ_A_N(SLOT, 1) }
+#else
+#define V7_READ_A(SLOT, NMT) V7_READ_A_N(SLOT, 4)
+#endif
 #define V7_READ_B(SLOT)                                                                                            \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
         fb[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                           \
         fb[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); }
+#define V7_MMA_N(QA, QB, N)                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+        _Pragma("unroll") for (int i = 0; i < (N); ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                acc[QA][QB][i][j] = AV_MFMA_F32_16X16X32_LP(fb[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0);
+#ifdef AV_V7_SKIP
+#define V7_MMA_BODY(QA, QB)                                                                                        \
+    { const int nm_ = (QA) ? nmt1 : nmt0;                                                                          \
+      if (nm_ == 4) { V7_MMA_N(QA, QB, 4) } else if (nm_ == 3) { V7_MMA_N(QA, QB, 3) }                             \
+      else if (nm_ == 2) { V7_MMA_N(QA, QB, 2) } else if (nm_ == 1) { V7_MMA_N(QA, QB, 1) } }
+#else
+#define V7_MMA_BODY(QA, QB) V7_MMA_N(QA, QB, 4)
+#endif
 #define V7_MMA(QA, QB)                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                                 \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i < ((QA) ? nmt1 : nmt0))                                \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-                acc[QA][QB][i][j] = AV_MFMA_F32_16X16X32_LP(fb[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0); \
+    V7_MMA_BODY(QA, QB)                                                                                            \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                  \
@@ -1436,15 +1449,21 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
             V7_MMA(1, 0)
         }
 #undef V7_READ_A
+#undef V7_READ_A_N
 #undef V7_READ_B
 #undef V7_MMA
+#undef V7_MMA_N
+#undef V7_MMA_BODY
         if (wr == 0) __builtin_amdgcn_s_barrier();           // balance the entry barrier of wavefronts 4-7: every fragment read of this tile has completed
         asm volatile("" ::: "memory");
         AV_STAMP7(seq, 2);
 
         // the ring is free: request the next tile's first two K-tiles, then store this tile from the registers
-        if (has_next) { prefetch(nm0, nn0); load_bias(nn0, bnext); }
+        if (has_next) { prefetch(nm0, nn0); bnext = load_bias(nn0); }
         const int m_end = m0 + rows_here;
+        float bv[8], bo[8];                                  // bias of my columns of B half 0 / 1 (rolled form: the two windows swap)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bv[e] = __shfl(bcur, g * 8 + e, 64); bo[e] = __shfl(bcur, 32 + g * 8 + e, 64); }
         constexpr bool ROLL = ACT != AV_ACT_MUL_AUX;
         if constexpr (!ROLL) {
             // saved-factor multiply (the dX product above an FFN activation): all 16 chunks unrolled, so that the factor loads of later chunks are
@@ -1457,15 +1476,12 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        v7_chunk<VO>(p, fl, acc[a][b][i][0], acc[a][b][i][1], bcur[b], m0 + a * 128 + (2 * i + wr) * 16 + r, n0 + wc * 64 + b * 32 + g * 8, m_end, cbase, R);
+                        v7_chunk<VO>(p, fl, acc[a][b][i][0], acc[a][b][i][1], b ? bo : bv, m0 + a * 128 + (2 * i + wr) * 16 + r, n0 + wc * 64 + b * 32 + g * 8, m_end, cbase, R);
         } else
         {
             // ONE copy of the epilogue body for four m-tiles (code size: it is inlined with every activation / dropout / residual branch).  The
             // quadrants (a, b) = (0,0) (0,1) (1,0) (1,1) pass through the registers of quadrant (0,0) - dead once stored - and the two bias
             // windows swap, so the rolled loop costs no registers
-            float bv[8], bo[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bv[e] = bcur[0][e]; bo[e] = bcur[1][e]; }
 #pragma unroll 1
             for (int qd = 0; qd < 4; ++qd) {
                 const int a = qd >> 1, b = qd & 1;
@@ -1825,10 +1841,10 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         for (int bm = V4_BM; bm >= 160; bm -= 16) {
             if (v4_bm && bm != v4_bm) continue;
             const long long t4 = (long long)av_cdiv(p.M, bm) * nbN4 * p.batch;
-            const double per_tile = nk * (0.25 + 1.34 * bm / 256.0) + 5.0 * bm / 256.0;
+            const double per_tile = nk * 1.55 + 4.0;      // us: every m-tile of the 256-row window is multiplied whatever bm is (see V4_READ_A); bm only sets the tile COUNT
             const long long r4 = t4 % 256;
             const bool tail = p.batch == 1 && v4_tail && t4 > 256 && r4 > 0 && r4 <= 128;
-            const double e = tail ? (double)(t4 / 256) * per_tile + (double)((4 * r4 + 255) / 256) * (nk * 0.45 + 3.0) : (double)((t4 + 255) / 256) * per_tile;
+            const double e = tail ? (double)(t4 / 256) * per_tile + (double)((4 * r4 + 255) / 256) * (nk * 0.8 + 4.0) : (double)((t4 + 255) / 256) * per_tile;   // a quadrant job: 16-18 us at K = 1024
             if (e < e4 * 0.98) { e4 = e; best_bm = bm; best_full = tail ? (int)(t4 - r4) : (int)t4; }
         }
         const long long t2 = (long long)av_cdiv(p.M, V2_BM) * av_cdiv(p.N, V2_BN) * p.batch;
