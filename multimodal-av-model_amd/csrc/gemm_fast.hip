@@ -1272,7 +1272,9 @@ __device__ __forceinline__ void v7_chunk(const av_gemm_args& p, const FastFlags&
 
 // ACT / ODT >= 0: the activation / output type are compile-time constants of this instantiation (the epilogue body shrinks to what the class
 // needs); -1: read from the arguments at run time.  VO: see epilogue_store_t.
-template <int ACT, int ODT, bool VO>
+// NM1: m-tiles per wavefront in the SECOND 128-row A half, a compile-time constant of the instantiation (4 = 256-row tiles; 3 = 224-row tiles:
+// both wavefront groups own three of its six live 16-row tiles, so no run-time test sits inside a cluster - see V7_MMA).
+template <int ACT, int ODT, bool VO, int NM1>
 __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm_args pa, const int nbM, const int nbN, const FastFlags fl, const int nfull, const int bm_eff) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(V4_LEAD == 8, "v7 assumes the 10-slot ring");
@@ -1354,8 +1356,6 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         int nm0 = 0, nn0 = 0, nmb = 0;
         if (has_next) coords(cs + nli, nm0, nn0, nmb);
         const int rows_here = p.M - m0 < bm_eff ? p.M - m0 : bm_eff;
-        auto ntiles = [&](int start) { int n = (rows_here - start + 31) >> 5; return n < 0 ? 0 : (n > 4 ? 4 : n); };       // my tiles start at rows start + 32 i
-        const int nmt0 = __builtin_amdgcn_readfirstlane(ntiles(wr * 16)), nmt1 = __builtin_amdgcn_readfirstlane(ntiles(128 + wr * 16));
 
         f32x4 acc[2][2][4][2];                               // [A half][B half][m-tile 2 i + wr][n-tile]; lane (g, r): row r of the m-tile, n-tile columns 4 g + e
 #pragma unroll
@@ -1379,43 +1379,26 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         AV_STAMP7(seq, 1);
 
         bf16x8 fa[4][2], fb[2][2];
-// The count of live m-tiles (nmt0 / nmt1: rows of a short tile) is wave-uniform: ONE scalar branch per read group / MFMA cluster selects a
-// straight-line body for that count.  A per-tile `if (i < nmt)` inside the unrolled loops compiles to a scalar branch around EVERY pair of
-// MFMAs and every pair of fragment reads - a dozen taken branches inside a 16-MFMA cluster that is meant to issue back to back.
-#define V7_READ_A_N(SLOT, N)                                                                                       \
+// Straight-line clusters: the count of m-tiles is a compile-time constant per A half (4 in half 0, NM1 in half 1).  A per-tile run-time test
+// (`if (i < nmt)`, the first form of the short-tile feature) compiled to a scalar branch around EVERY pair of MFMAs and fragment reads - a dozen
+// taken branches inside a 16-MFMA cluster that is meant to issue back to back (profiles/r04_branch_free_clusters_ab.txt: 15-20 % of the loop).
+#define V7_READ_A(SLOT, N)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < (N); ++i) {                                                              \
         fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 4096 + ch0);                           \
         fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 4096 + ch1); }
-#ifdef AV_V7_SKIP
-#define V7_READ_A(SLOT, NMT)                                                                                       \
-    if ((NMT) == 4) { V7_READ_A_N(SLOT, 4) } else if ((NMT) == 3) { V7_READ_A_N(SLOT, 3) }                         \
-    else if ((NMT) == 2) { V7_READ_A_N(SLOT, 2) } else if ((NMT) == 1) { V7_READ_A_N(SLOT, 1) }
-#else
-#define V7_READ_A(SLOT, NMT) V7_READ_A_N(SLOT, 4)
-#endif
 #define V7_READ_B(SLOT)                                                                                            \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
         fb[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                           \
         fb[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); }
-#define V7_MMA_N(QA, QB, N)                                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
-        _Pragma("unroll") for (int i = 0; i < (N); ++i)                                                            \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-                acc[QA][QB][i][j] = AV_MFMA_F32_16X16X32_LP(fb[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0);
-#ifdef AV_V7_SKIP
-#define V7_MMA_BODY(QA, QB)                                                                                        \
-    { const int nm_ = (QA) ? nmt1 : nmt0;                                                                          \
-      if (nm_ == 4) { V7_MMA_N(QA, QB, 4) } else if (nm_ == 3) { V7_MMA_N(QA, QB, 3) }                             \
-      else if (nm_ == 2) { V7_MMA_N(QA, QB, 2) } else if (nm_ == 1) { V7_MMA_N(QA, QB, 1) } }
-#else
-#define V7_MMA_BODY(QA, QB) V7_MMA_N(QA, QB, 4)
-#endif
-#define V7_MMA(QA, QB)                                                                                             \
+#define V7_MMA(QA, QB, N)                                                                                          \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                                 \
-    V7_MMA_BODY(QA, QB)                                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+        _Pragma("unroll") for (int i = 0; i < (N); ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                acc[QA][QB][i][j] = AV_MFMA_F32_16X16X32_LP(fb[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0);     \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                  \
@@ -1432,28 +1415,25 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
             b4 += 4; b4 = b4 >= V4_NS ? b4 - V4_NS : b4;
             V7_READ_B(3)
             __builtin_amdgcn_sched_barrier(0);
-            V7_READ_A(0, nmt0)
+            V7_READ_A(0, 4)
             if (4 * t + V4_LEAD + 0 < nh) issue(m0, n0, t + 2, 0, si[0]);
-            V7_MMA(0, 0)
+            V7_MMA(0, 0, 4)
             V7_READ_B(1)
             if (4 * t + V4_LEAD + 1 < nh) issue(m0, n0, t + 2, 1, si[1]);
-            V7_MMA(0, 1)
-            V7_READ_A(2, nmt1)
+            V7_MMA(0, 1, 4)
+            V7_READ_A(2, NM1)
             if (4 * t + V4_LEAD + 2 < nh) issue(m0, n0, t + 2, 2, si[2]);
-            V7_MMA(1, 1)
+            V7_MMA(1, 1, NM1)
             V7_READ_B(3)
             if (4 * t + V4_LEAD + 3 < nh) {
                 issue(m0, n0, t + 2, 3, si[3]);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            V7_MMA(1, 0)
+            V7_MMA(1, 0, NM1)
         }
 #undef V7_READ_A
-#undef V7_READ_A_N
 #undef V7_READ_B
 #undef V7_MMA
-#undef V7_MMA_N
-#undef V7_MMA_BODY
         if (wr == 0) __builtin_amdgcn_s_barrier();           // balance the entry barrier of wavefronts 4-7: every fragment read of this tile has completed
         asm volatile("" ::: "memory");
         AV_STAMP7(seq, 2);
@@ -1835,13 +1815,21 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         const int nbN4 = av_cdiv(p.N, V4_BN);
         static const int v4_tail = [] { const char* e = getenv("AVAMD_GEMM_V4_TAIL"); return e ? atoi(e) : 1; }();
         static const int v4_bm = [] { const char* e = getenv("AVAMD_GEMM_V4_BM"); return e ? atoi(e) : 0; }();     // 0: choose; else force (multiple of 16)
-        // row-tile height: the tile time scales with the rows that get MFMAs (1.59 us per K-tile at 256 rows, measured; ~0.25 us of it does
-        // not scale), the count of tiles with their number; candidates keep whole 16-row tiles
+        static const int v7_mode = [] { const char* e = getenv("AVAMD_GEMM_V7"); return e ? atoi(e) : 1; }();
+        // persistent form (see the kernel's notes): specialised per epilogue class; the classes need whole 16-B chunks everywhere
+        // (epilogue_store_t<true>) - anything else stays on the v4 kernel
+        const bool v7_vo = p.N % 8 == 0 && fl.c_vec && (!p.R || fl.r_vec) && (!p.aux || fl.aux_vec);
+        const bool v7_cls = (p.out_dtype == AV_BF16 && (p.act == AV_ACT_NONE || p.act == AV_ACT_GELU || p.act == AV_ACT_GELU_GF || p.act == AV_ACT_MUL_AUX)) ||
+                            (p.out_dtype == AV_F32 && p.act == AV_ACT_NONE);
+        const bool v7_ok = v7_mode > 0 && v7_vo && v7_cls;
+        // row-tile height bm (a multiple of 16, rows of the 256-row window a tile owns): it sets the tile COUNT (248 tiles of 208 rows fill 256 CUs
+        // where 200 of 256 rows leave 56 idle), and - v7 only - tiles of <= 224 rows run the instantiation whose second A half multiplies three
+        // m-tiles per wavefront instead of four (NM1 = 3: 7/8 of the MFMAs; measured ~0.9 of the tile time)
         int best_bm = V4_BM; double e4 = 1e30; int best_full = 0;
         for (int bm = V4_BM; bm >= 160; bm -= 16) {
             if (v4_bm && bm != v4_bm) continue;
             const long long t4 = (long long)av_cdiv(p.M, bm) * nbN4 * p.batch;
-            const double per_tile = nk * 1.55 + 4.0;      // us: every m-tile of the 256-row window is multiplied whatever bm is (see V4_READ_A); bm only sets the tile COUNT
+            const double per_tile = nk * 1.55 * ((v7_ok && bm <= 224) ? 0.9 : 1.0) + 4.0;      // us
             const long long r4 = t4 % 256;
             const bool tail = p.batch == 1 && v4_tail && t4 > 256 && r4 > 0 && r4 <= 128;
             const double e = tail ? (double)(t4 / 256) * per_tile + (double)((4 * r4 + 255) / 256) * (nk * 0.8 + 4.0) : (double)((t4 + 255) / 256) * per_tile;   // a quadrant job: 16-18 us at K = 1024
@@ -1851,13 +1839,7 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
         const long long t1 = (long long)av_cdiv(p.M, BM) * av_cdiv(p.N, 128) * p.batch;
         const double e2 = (double)((t2 + 255) / 256) * (nk * 0.85 + 2.0);
         const double e1 = (double)((t1 + 511) / 512) * (nk * 1.0 + 2.5);
-        static const int v7_mode = [] { const char* e = getenv("AVAMD_GEMM_V7"); return e ? atoi(e) : 1; }();
-        // persistent form (see the kernel's notes): specialised per epilogue class; the classes need whole 16-B chunks everywhere
-        // (epilogue_store_t<true>) - anything else stays on the v4 kernel
-        const bool v7_vo = p.N % 8 == 0 && fl.c_vec && (!p.R || fl.r_vec) && (!p.aux || fl.aux_vec);
-        const bool v7_cls = (p.out_dtype == AV_BF16 && (p.act == AV_ACT_NONE || p.act == AV_ACT_GELU || p.act == AV_ACT_GELU_GF || p.act == AV_ACT_MUL_AUX)) ||
-                            (p.out_dtype == AV_F32 && p.act == AV_ACT_NONE);
-        if (v7_mode > 0 && v7_vo && v7_cls && (v7_mode >= 2 || v4_mode >= 2 || e4 < (v2_ok ? (e2 < e1 ? e2 : e1) : e1))) {
+        if (v7_ok && (v7_mode >= 2 || v4_mode >= 2 || e4 < (v2_ok ? (e2 < e1 ? e2 : e1) : e1))) {
             static int ncu = 0;
             if (!ncu) {
                 int dev = 0;
@@ -1883,11 +1865,12 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
                 }
                 hipLaunchKernelGGL(kern, dim3((unsigned)G, 1, (unsigned)p.batch), dim3(V4_NT), V4_LDS, st, p, nbM, nbN4, fl, nfull, best_bm);
             };
-            if (p.out_dtype == AV_F32) go(gemm_nt_bf16_v7_kernel<AV_ACT_NONE, AV_F32, true>);
-            else if (p.act == AV_ACT_NONE) go(gemm_nt_bf16_v7_kernel<AV_ACT_NONE, AV_BF16, true>);
-            else if (p.act == AV_ACT_GELU) go(gemm_nt_bf16_v7_kernel<AV_ACT_GELU, AV_BF16, true>);
-            else if (p.act == AV_ACT_GELU_GF) go(gemm_nt_bf16_v7_kernel<AV_ACT_GELU_GF, AV_BF16, true>);
-            else go(gemm_nt_bf16_v7_kernel<AV_ACT_MUL_AUX, AV_BF16, true>);
+            const bool nm3 = best_bm <= 224;                 // tiles of <= 224 rows: three m-tiles per wavefront in the second A half
+            if (p.out_dtype == AV_F32) { if (nm3) go(gemm_nt_bf16_v7_kernel<AV_ACT_NONE, AV_F32, true, 3>); else go(gemm_nt_bf16_v7_kernel<AV_ACT_NONE, AV_F32, true, 4>); }
+            else if (p.act == AV_ACT_NONE) { if (nm3) go(gemm_nt_bf16_v7_kernel<AV_ACT_NONE, AV_BF16, true, 3>); else go(gemm_nt_bf16_v7_kernel<AV_ACT_NONE, AV_BF16, true, 4>); }
+            else if (p.act == AV_ACT_GELU) { if (nm3) go(gemm_nt_bf16_v7_kernel<AV_ACT_GELU, AV_BF16, true, 3>); else go(gemm_nt_bf16_v7_kernel<AV_ACT_GELU, AV_BF16, true, 4>); }
+            else if (p.act == AV_ACT_GELU_GF) { if (nm3) go(gemm_nt_bf16_v7_kernel<AV_ACT_GELU_GF, AV_BF16, true, 3>); else go(gemm_nt_bf16_v7_kernel<AV_ACT_GELU_GF, AV_BF16, true, 4>); }
+            else { if (nm3) go(gemm_nt_bf16_v7_kernel<AV_ACT_MUL_AUX, AV_BF16, true, 3>); else go(gemm_nt_bf16_v7_kernel<AV_ACT_MUL_AUX, AV_BF16, true, 4>); }
             if (rc != AV_OK) return rc;
             AV_LAUNCH_CHECK();
             return AV_OK;
