@@ -212,7 +212,7 @@ __device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const Fa
         for (int e = 0; e < 8; ++e) m[e] = 1.f;
         if (p.drop_p > 0.f) {
             const float ik = 1.0f / (1.0f - p.drop_p);
-            if ((off & 3) == 0) {
+            if (VO || (off & 3) == 0) {                       // VO: chunks are 16-B aligned (8-element offsets) by contract
                 float m4[4];
                 drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
 #pragma unroll
@@ -285,7 +285,7 @@ __device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const Fa
     }
     if (p.drop_p > 0.f && p.act != AV_ACT_GELU_GF) {
         const float ik = 1.0f / (1.0f - p.drop_p);
-        if ((off & 3) == 0) {
+        if (VO || (off & 3) == 0) {
             float m4[4];
             drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
 #pragma unroll
