@@ -164,6 +164,49 @@ __device__ __forceinline__ void gelu_both_fast2(av_f32x2 x, av_f32x2& gl, av_f32
     const av_f32x2 h = pk_splat(-0.5f) * x * x;
     gp = pk_fma(x * pk_splat(0.39894228040143267794f), av_f32x2{__expf(h.x), __expf(h.y)}, pk_fma(sg, e, pk_splat(0.5f)));
 }
+// The same functions over FOUR pairs at once, written coefficient by coefficient: each pair's Horner chain is 9 dependent packed FMAs, and
+// evaluated pair after pair (as the per-pair functions above inline) the compiler emits four serial chains with a wait state between every two
+// instructions - an epilogue that is bound by vector issue then runs at the latency of one chain.  Side by side the four chains fill each
+// other's latency.  Per element the operations and their order are those of the per-pair functions: bit-identical results.
+__device__ __forceinline__ void erf_abs_poly2x4(const av_f32x2 (&z)[4], av_f32x2 (&e)[4]) {
+    av_f32x2 z2[4], p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { z2[k] = z[k] * z[k]; p[k] = pk_splat(4.0719861260640755e-08f); }
+    constexpr float cf[8] = {-1.9457509097264847e-06f, 4.110950976610184e-05f, -0.0005118074477650225f, 0.004241328686475754f,
+                             -0.025126988068223f, 0.11113087832927704f, -0.37536558508872986f, 1.1282844543457031f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = pk_fma(p[k], z2[k], pk_splat(cf[c]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e[k] = p[k] * z[k];
+        e[k].x = z[k].x >= 3.0f ? 1.0f : e[k].x;
+        e[k].y = z[k].y >= 3.0f ? 1.0f : e[k].y;
+    }
+}
+__device__ __forceinline__ void gelu_fast2x4(const av_f32x2 (&x)[4], av_f32x2 (&g)[4]) {
+    av_f32x2 z[4], e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = pk_abs(x[k]) * pk_splat(0.70710678118654752440f);
+    erf_abs_poly2x4(z, e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const av_f32x2 t = pk_splat(0.5f) * x[k]; g[k] = pk_fma(pk_abs(t), e[k], t); }
+}
+__device__ __forceinline__ void gelu_both_fast2x4(const av_f32x2 (&x)[4], av_f32x2 (&gl)[4], av_f32x2 (&gp)[4]) {
+    av_f32x2 z[4], e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = pk_abs(x[k]) * pk_splat(0.70710678118654752440f);
+    erf_abs_poly2x4(z, e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const av_f32x2 t = pk_splat(0.5f) * x[k];
+        gl[k] = pk_fma(pk_abs(t), e[k], t);
+        const av_f32x2 sg = av_f32x2{x[k].x < 0.f ? -0.5f : 0.5f, x[k].y < 0.f ? -0.5f : 0.5f};
+        const av_f32x2 h = pk_splat(-0.5f) * x[k] * x[k];
+        gp[k] = pk_fma(x[k] * pk_splat(0.39894228040143267794f), av_f32x2{__expf(h.x), __expf(h.y)}, pk_fma(sg, e[k], pk_splat(0.5f)));
+    }
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---- counter-based RNG for dropout: the mask of element `idx` of stream `stream` under `seed` is a pure function of (seed, stream, idx),

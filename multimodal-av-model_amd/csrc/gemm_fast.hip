@@ -225,13 +225,17 @@ __device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const Fa
                 for (int e = 0; e < 8; ++e) m[e] = drop_mult(p.drop_seed, p.drop_stream, (unsigned long long)(off + e), p.drop_p, ik);
             }
         }
+        {
+            av_f32x2 x4[4], gl4[4], gp4[4];                     // the four pairs side by side (av_common.h: gelu_both_fast2x4)
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            av_f32x2 gl, gp;
-            const av_f32x2 mm = av_f32x2{m[e], m[e + 1]};
-            gelu_both_fast2(av_f32x2{v[e], v[e + 1]}, gl, gp);
-            gl = gl * mm; gp = gp * mm;
-            v[e] = gl.x; v[e + 1] = gl.y; gf[e] = gp.x; gf[e + 1] = gp.y;
+            for (int k = 0; k < 4; ++k) x4[k] = av_f32x2{v[2 * k], v[2 * k + 1]};
+            gelu_both_fast2x4(x4, gl4, gp4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const av_f32x2 mm = av_f32x2{m[2 * k], m[2 * k + 1]};
+                const av_f32x2 gl = gl4[k] * mm, gp = gp4[k] * mm;
+                v[2 * k] = gl.x; v[2 * k + 1] = gl.y; gf[2 * k] = gp.x; gf[2 * k + 1] = gp.y;
+            }
         }
         if (p.C2) {
             if (full && fl.c_vec && p.out_dtype == AV_BF16) {
@@ -262,8 +266,12 @@ __device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const Fa
         }
     }
     if (p.act == AV_ACT_GELU) {
+        av_f32x2 x4[4], g4[4];
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) { const av_f32x2 g = gelu_fast2(av_f32x2{v[e], v[e + 1]}); v[e] = g.x; v[e + 1] = g.y; }
+        for (int k = 0; k < 4; ++k) x4[k] = av_f32x2{v[2 * k], v[2 * k + 1]};
+        gelu_fast2x4(x4, g4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = g4[k].x; v[2 * k + 1] = g4[k].y; }
     } else if (p.act == AV_ACT_MUL_AUX) {
         if (full && fl.aux_vec && p.aux_dtype == AV_BF16) {
             const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + off);
