@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
                 float pd = pv;
                 if (p.drop_p > 0.f) {
                     const unsigned long long idx = (((unsigned long long)b * p.H + h) * p.Tq + (q0 + w * 16 + 4 * g + e)) * ((p.Tk + 3) & ~3) + (k0 + j * 16 + r);   // row pitch padded to 4: see attn_common.h
-                    pd *= drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                    pd *= drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, drop_inv_keep(p.drop_p));
                 }
                 Pw[(4 * g + e) * LDV + j * 16 + r] = from_f32<T>(pd);
             }

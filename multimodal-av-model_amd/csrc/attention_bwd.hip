@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const BwdP p) {
                 float dm = 1.f;                                     // dropout multiplier of P[q][key] (same mask as the forward)
                 if (p.drop_p > 0.f) {
                     const unsigned long long idx = (((unsigned long long)b * p.H + h) * p.Tq + (i0 + qc)) * ((p.Tk + 3) & ~3) + key;
-                    dm = drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                    dm = drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, drop_inv_keep(p.drop_p));
                 }
                 const float ds = pv * (dpt[e] * dm - dl) * p.scale;
                 Pme[(4 * g + e) * LDT + qc] = (T)(pv * dm);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const BwdP p) {
                 float dm = 1.f;
                 if (p.drop_p > 0.f) {
                     const unsigned long long idx = (((unsigned long long)b * p.H + h) * p.Tq + (i0 + w * 16 + 4 * g + e)) * ((p.Tk + 3) & ~3) + (j0 + n * 16 + r);
-                    dm = drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                    dm = drop_mult_call(p.drop_seed, p.drop_stream, idx, p.drop_p, drop_inv_keep(p.drop_p));
                 }
                 Sme[(4 * g + e) * LDT + n * 16 + r] = (T)(pv * (dpt[e] * dm - drow[e]) * p.scale);
             }

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short_kernel(const AttnP p) {
                 S[t][e] = pv;
             }
         if (DROP) {
-            const float ik = 1.0f / (1.0f - p.drop_p);
+            const float ik = drop_inv_keep(p.drop_p);
             if constexpr (DROP == 2) {
                 // keep bits precomputed by attn_dropmask_kernel (the same Philox masks, evaluated ONCE per step and element instead of in the
                 // forward and in both phases of the backward): bit 4 t + e of my word <-> key 16 t + 4 g + e of my query
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
             }
         float ikf = 1.0f;                                       // DROP 2: 1 / (1 - p) multiplies the normalisation instead of every probability
         if (DROP) {
-            const float ik = 1.0f / (1.0f - p.drop_p);
+            const float ik = drop_inv_keep(p.drop_p);
             if constexpr (DROP == 2) {
                 ikf = ik;
 #pragma unroll
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_long_kernel(const AttnP p) {
                 S[t][e] = pv;
             }
         if (DROP) {
-            const float ik = 1.0f / (1.0f - p.drop_p);
+            const float ik = drop_inv_keep(p.drop_p);
             const unsigned long long base = (((unsigned long long)b * p.H + h) * p.Tq + qrow) * ((p.Tk + 3) & ~3) + k0;
 #pragma unroll
             for (int t = 0; t < 2 * NKP; ++t) {
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_short_kernel(const BwdP p, int
     const bf16_t* DO = p.dout + (long long)b * p.do_bs + (long long)h * 64;
     const float* lse = p.lse + ((long long)b * p.H + h) * p.Tq;
     const float c = p.scale * LOG2E;
-    const float ik = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const float ik = DROP ? drop_inv_keep(p.drop_p) : 1.0f;
     const unsigned long long dbase = ((unsigned long long)b * p.H + h) * p.Tq;
     const int nqt_m = (p.Tq + 15) >> 4;                         // stored keep bits: [b][h][query tile][lane] x 64 bits (forward kernel)
     const long long dbase_m = ((long long)b * p.H + h) * nqt_m;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_long_kv_kernel(const BwdP p) {
     const bf16_t* DO = p.dout + (long long)b * p.do_bs + (long long)h * 64;
     const float* lse = p.lse + ((long long)b * p.H + h) * p.Tq;
     const float c = p.scale * LOG2E;
-    const float ik = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const float ik = DROP ? drop_inv_keep(p.drop_p) : 1.0f;
     const unsigned long long dbase = ((unsigned long long)b * p.H + h) * p.Tq;
     const int kt = blockIdx.z * NW + w;                         // my 16-key tile (wave-uniform)
     const bool active = kt * 16 < p.Tk;
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_long_q_kernel(const BwdP p) {
     const bf16_t* DO = p.dout + (long long)b * p.do_bs + (long long)h * 64;
     const float* lse = p.lse + ((long long)b * p.H + h) * p.Tq;
     const float c = p.scale * LOG2E;
-    const float ik = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const float ik = DROP ? drop_inv_keep(p.drop_p) : 1.0f;
     const unsigned long long dbase = ((unsigned long long)b * p.H + h) * p.Tq;
     const int qt = blockIdx.z * NW + w;
     const bool active = qt * 16 < p.Tq;

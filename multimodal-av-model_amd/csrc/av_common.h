@@ -211,9 +211,9 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 
 // ---- counter-based RNG for dropout: the mask of element `idx` of stream `stream` under `seed` is a pure function of (seed, stream, idx),
 // so the backward pass regenerates exactly the forward's mask without storing it.  An aligned group of four elements draws 64 bits = FOUR
-// 16-bit uniforms (the drop probability is resolved to 2^-16) from a bijective 32-bit integer mixer - two multiply-xorshift rounds with the
-// "lowbias32" constants of C. Wellons' hash prospector (avalanche bias 0.17) - evaluated at two inputs derived from the group index and a
-// 32-bit key mixed from seed and stream.  Rounds 1-2 of this build used Philox2x32-10 here: its ten 32 x 32 -> 64-bit multiplies per group
+// 16-bit uniforms (the drop probability is resolved to 2^-16) from a keyed 32-bit integer mixer - two multiply-xorshift rounds with the
+// "lowbias32" constants of C. Wellons' hash prospector (avalanche bias 0.17), a second key xor-ed in between them - evaluated at two inputs
+// derived from the group index and a 32-bit key mixed from seed and stream.  Rounds 1-2 of this build used Philox2x32-10 here: its ten 32 x 32 -> 64-bit multiplies per group
 // (v_mul_lo_u32 + v_mul_hi_u32, quarter-rate instructions) were a quarter of the FFN-up GEMM's epilogue time while its matrix pipes idled;
 // the mixer needs four.  Dropout needs decorrelated, reproducible masks, not a cryptographic stream.
 __device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned stream) {
@@ -223,16 +223,35 @@ __device__ __forceinline__ unsigned drop_key(unsigned long long seed, unsigned s
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return h;
 }
-__device__ __forceinline__ unsigned mix32(unsigned x) {
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+// second key of a (seed, stream) pair, folded in BETWEEN the mixer's two rounds: with the first key alone (x = group ^ key, then a fixed
+// bijection) every stream's mask would be an XOR-translated window of one 2^32-entry table, so the ~150 masks of a step would be permuted
+// copies of overlapping windows; with a second, independently mixed key after the first multiply two streams are not translates of each other.
+__device__ __forceinline__ unsigned drop_key2(unsigned key) {
+    unsigned h = __builtin_rotateleft32(key, 16) * 0x9E3779B1u + 0x7F4A7C15u;
+    h ^= h >> 13; h *= 0x5BD1E995u; h ^= h >> 15;
+    return h;
+}
+__device__ __forceinline__ unsigned mix32(unsigned x, unsigned k2) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= k2; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
+}
+// a group index -> its two 32-bit draws (four 16-bit uniforms)
+__device__ __forceinline__ void drop_draw(unsigned long long seed, unsigned stream, unsigned long long idx4, unsigned& o0, unsigned& o1) {
+    const unsigned long long blk = idx4 >> 2;
+    const unsigned c1 = (unsigned)(blk >> 32);                                     // non-zero only beyond 2^34 elements
+    const unsigned key = drop_key(seed, stream), k2 = drop_key2(key);
+    const unsigned x = (unsigned)blk ^ key ^ c1 ^ __builtin_rotateleft32(c1, 11) ^ __builtin_rotateleft32(c1, 23);
+    o0 = mix32(x, k2); o1 = mix32(x + 0x9E3779B9u, k2);
+}
+// The keep test resolves p to thr = ceil(65536 p) sixteen-bit steps, so the kept fraction is (65536 - thr) / 65536, not 1 - p: the survivors
+// are scaled by the inverse of THAT (an unbiased mask; with 1 / (1 - p) the expectation was off by up to 1.5e-5 relative).
+__device__ __host__ __forceinline__ float drop_inv_keep(float p) {
+    const float thr = __builtin_ceilf(p * 65536.0f);
+    return 65536.0f / (65536.0f - thr);
 }
 // the four 16-bit uniforms (as floats in [0,1)) of the aligned group that starts at element idx4 (a multiple of 4)
 __device__ __forceinline__ void drop_uniform4(unsigned long long seed, unsigned stream, unsigned long long idx4, float (&u)[4]) {
-    const unsigned long long blk = idx4 >> 2;
-    const unsigned c1 = (unsigned)(blk >> 32);                                     // non-zero only beyond 2^34 elements
-    const unsigned x = (unsigned)blk ^ drop_key(seed, stream) ^ c1 ^ __builtin_rotateleft32(c1, 11) ^ __builtin_rotateleft32(c1, 23);
-    const unsigned o0 = mix32(x), o1 = mix32(x + 0x9E3779B9u);
+    unsigned o0, o1; drop_draw(seed, stream, idx4, o0, o1);
     u[0] = (float)(o0 & 0xFFFFu) * (1.0f / 65536.0f); u[1] = (float)(o0 >> 16) * (1.0f / 65536.0f);
     u[2] = (float)(o1 & 0xFFFFu) * (1.0f / 65536.0f); u[3] = (float)(o1 >> 16) * (1.0f / 65536.0f);
 }
@@ -253,19 +272,13 @@ __device__ __noinline__ float drop_mult_call(unsigned long long seed, unsigned s
 }
 // keep bits (bit e = element idx4 + e is kept) of an aligned group of four under drop probability p (thr = ceil(65536 p))
 __device__ __forceinline__ unsigned drop_keep4(unsigned long long seed, unsigned stream, unsigned long long idx4, unsigned thr) {
-    const unsigned long long blk = idx4 >> 2;
-    const unsigned c1 = (unsigned)(blk >> 32);
-    const unsigned x = (unsigned)blk ^ drop_key(seed, stream) ^ c1 ^ __builtin_rotateleft32(c1, 11) ^ __builtin_rotateleft32(c1, 23);
-    const unsigned o0 = mix32(x), o1 = mix32(x + 0x9E3779B9u);
+    unsigned o0, o1; drop_draw(seed, stream, idx4, o0, o1);
     return ((o0 & 0xFFFFu) >= thr ? 1u : 0u) | ((o0 >> 16) >= thr ? 2u : 0u) | ((o1 & 0xFFFFu) >= thr ? 4u : 0u) | ((o1 >> 16) >= thr ? 8u : 0u);
 }
 // 4 consecutive elements starting at a multiple of 4 (one generator call).  The keep test runs on the 16-bit integers: u = k / 65536 >= p
 // <=> k >= ceil(65536 p) (both sides exact in fp32), which spares the int -> float conversion and the scaling of every element.
 __device__ __forceinline__ void drop_mult4(unsigned long long seed, unsigned stream, unsigned long long idx4, float p, float inv_keep, float (&m)[4]) {
-    const unsigned long long blk = idx4 >> 2;
-    const unsigned c1 = (unsigned)(blk >> 32);
-    const unsigned x = (unsigned)blk ^ drop_key(seed, stream) ^ c1 ^ __builtin_rotateleft32(c1, 11) ^ __builtin_rotateleft32(c1, 23);
-    const unsigned o0 = mix32(x), o1 = mix32(x + 0x9E3779B9u);
+    unsigned o0, o1; drop_draw(seed, stream, idx4, o0, o1);
     const unsigned thr = (unsigned)__builtin_ceilf(p * 65536.0f);
     m[0] = (o0 & 0xFFFFu) >= thr ? inv_keep : 0.f; m[1] = (o0 >> 16) >= thr ? inv_keep : 0.f;
     m[2] = (o1 & 0xFFFFu) >= thr ? inv_keep : 0.f; m[3] = (o1 >> 16) >= thr ? inv_keep : 0.f;

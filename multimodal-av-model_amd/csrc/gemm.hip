@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const av_gemm_args p, const in
                     float v = acc[i][j][e] * p.alpha + bias;
                     const long long off = cbase + (long long)m * p.ldc + n;
                     if (p.act == AV_ACT_GELU_GF) {               // C2 = gelu'(v) * m, v = gelu(v) * m
-                        const float mlt = p.drop_p > 0.f ? drop_mult_call(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, 1.0f / (1.0f - p.drop_p)) : 1.f;
+                        const float mlt = p.drop_p > 0.f ? drop_mult_call(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, drop_inv_keep(p.drop_p)) : 1.f;
                         if (p.C2) st_any(p.C2, off, p.out_dtype, gelu_grad_f(v) * mlt);
                         v = gelu_f(v) * mlt;
                     } else {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const av_gemm_args p, const in
                         if (p.act == AV_ACT_GELU) v = gelu_f(v);
                         else if (p.act == AV_ACT_MUL_GELU_GRAD) v *= gelu_grad_f(ld_any(p.aux, off, p.aux_dtype));
                         else if (p.act == AV_ACT_MUL_AUX) v *= ld_any(p.aux, off, p.aux_dtype);
-                        if (p.drop_p > 0.f) v *= drop_mult_call(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, 1.0f / (1.0f - p.drop_p));
+                        if (p.drop_p > 0.f) v *= drop_mult_call(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, drop_inv_keep(p.drop_p));
                     }
                     if (R) v += R[(long long)m * p.ldr + n];
                     st_any(p.C, off, p.out_dtype, v);

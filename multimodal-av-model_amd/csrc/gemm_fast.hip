@@ -65,18 +65,84 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, long
 // with s(row) = ((row & 3) << 2) | ((row >> 2) & 3) (applied to the DMA source), which makes those reads bank-conflict free.
 typedef __attribute__((address_space(3))) bf16x4* lds_b4_t;
 
+template <int NWI = 4>                                       // wave instructions per wavefront: 4 (four wavefronts fill the tile) or 2 (eight)
 __device__ __forceinline__ void stage_kmajor(const bf16_t* __restrict__ base, long long ld, int col0, int ncols, int k0, int K, char* tile,
                                              int w, int lane) {
     const int rsub = lane >> 4, pos = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (w * 4 + i) * 4 + rsub;
+    for (int i = 0; i < NWI; ++i) {
+        const int row = (w * NWI + i) * 4 + rsub;
         const int sx = ((row & 3) << 2) | ((row >> 2) & 3);
         const int col = col0 + ((pos ^ sx) << 3), k = k0 + row;
         const bf16_t* src = (k < K && col < ncols) ? base + (long long)k * ld + col : (const bf16_t*)g_zero_line;
-        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 4 + i) * 1024));
+        const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * NWI + i) * 1024));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
     }
+}
+
+// ---- k-major half-tiles of the 8-phase kernel (gemm_nt_bf16_v4_kernel<false, true>) ---------------------------------------------------------
+// Image of a half-tile [64 k-rows][128 columns]: 8-row x 32-column subtiles of 512 B,
+//     off(row, ch) = 2048 (row >> 3) + 512 (ch >> 2) + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3))          (ch = 16-B chunk of the row)
+// - a 32-lane half of a transposed read (8 k-rows x 32 B) covers all 64 banks once, and the offset of column tile ct, k-step ks splits into a
+// per-lane base that depends on ct only through its parity and a COMPILE-TIME part 8192 ks + 512 (ct >> 1): the reads take it as the
+// instruction's immediate offset (4 address adds per half-tile instead of one per read).
+// LDS-DMA: wave instruction q = 2 w + i of a half-tile fills bytes [1024 q, 1024 q + 1024) = rows 8 (q >> 1) .. + 7 x columns 64 (q & 1) .. + 63,
+// each lane quad 64 contiguous bytes of one row (lane l: row 8 (q >> 1) + ((l >> 2) & 7), chunk 4 (2 (q & 1) + (l >> 5)) + ((l & 3) ^ x)).
+// The lane-dependent part of the source address is hoisted out of the K loop (row * ld + col as a 32-bit element offset, the K-tile adds the
+// wave-uniform k0 * ld), and the common path has NO per-lane select: the instructions between a phase's fragment reads and its barrier are on
+// the critical path of the staggered schedule - with the (k < K && col < ncols ? src : zero line) select of stage_kmajor in front of every
+// LDS-DMA (compare, mask, two v_cndmask, a 64-bit multiply) the DMA-only loop ran at 1.78 us per K-tile, without it at 1.19 (row-major form: 1.03).
+struct KmLane { int off[2]; };
+__device__ __forceinline__ void km_lane_init(KmLane& kl, long long ld, int col0, int ncols, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = w * 2 + i;
+        const int row = 8 * (q >> 1) + ((lane >> 2) & 7);
+        const int x = (((q >> 1) & 1) << 1) | ((lane >> 4) & 1);                    // (row >> 2) & 3
+        int col = col0 + 8 * (4 * (2 * (q & 1) + (lane >> 5)) + ((lane & 3) ^ x));
+        if (col > ncols - 8) col = ncols - 8;                    // columns past the operand: clamped re-reads, multiplied and never stored (ncols % 8 == 0)
+        kl.off[i] = row * (int)ld + col;
+    }
+}
+__device__ __forceinline__ void stage_kmajor8(const bf16_t* __restrict__ base, long long ld, const KmLane& kl, int k0, int K, char* tile, int w, int lane) {
+    const bf16_t* tb = base + (long long)k0 * ld;                // wave-uniform
+    if (k0 + 64 <= K) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 2 + i) * 1024));
+            __builtin_amdgcn_global_load_lds((gptr_t)(tb + kl.off[i]), (lptr_t)(tile + off), 16, 0, 0);
+        }
+    } else {                                                     // a slice's ragged last K-tile: k-rows beyond it come from the zero line
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * w + ((lane >> 2) & 7);           // 8 ((2 w + i) >> 1) + ...
+            const bf16_t* src = k0 + row < K ? tb + kl.off[i] : (const bf16_t*)g_zero_line;
+            const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 2 + i) * 1024));
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + off), 16, 0, 0);
+        }
+    }
+}
+// per-lane base offsets of the transposed reads: [parity of the column tile][rows 8 g + 0..3 | 8 g + 4..7]; `fold` = the wave-uniform part of
+// 512 (ct >> 1) (A: 1024 wr, B: 512 wc)
+struct Km8Base { unsigned b[2][2]; };
+__device__ __forceinline__ void km8_base_init(Km8Base& kb, int fold, int lane) {
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi)
+            kb.b[e][hi] = (unsigned)(fold + 2048 * g + 64 * qq + 256 * hi + 32 * (e ^ (g & 1)) + 16 * ((pp >> 1) ^ hi) + 8 * (pp & 1));
+}
+template <int IMM>
+__device__ __forceinline__ bf16x4 ds_read_tr16_b64_imm(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+    return v;
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8 km8_frag(unsigned lo_addr, unsigned hi_addr) {
+    const bf16x4 lo = ds_read_tr16_b64_imm<IMM>(lo_addr), hi = ds_read_tr16_b64_imm<IMM>(hi_addr);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // per-lane byte offsets (inside a k-major tile, k-step 0) of the two transposed reads of column tile `ct`
@@ -91,9 +157,20 @@ __device__ __forceinline__ KmOff kmajor_off(int ct, int lane) {
     o.hi = r2 * 256 + ((ch ^ s2) << 4) + 8 * (pp & 1);
     return o;
 }
+// The transposed reads are issued as inline asm, not through the builtin: next to LDS-DMA the compiler puts `s_waitcnt vmcnt(0)` in front of every
+// group of builtin transposed reads (it cannot tell which in-flight global_load_lds they depend on), i.e. the whole prefetch queue drained before
+// each fragment read - measured: the 128 x 128 kernel below ran its k-major products load -> compute serialised (22 % MFMA-busy), and the
+// 8-phase form at 2.7 us per K-tile instead of 1.55.  The asm form is invisible to that pass: the CALLER waits (lgkmcnt(0) before the MFMAs that
+// consume the fragments; vmcnt for the DMA as for the row-major tiles).
+__device__ __forceinline__ bf16x4 ds_read_tr16_b64_asm(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
 __device__ __forceinline__ bf16x8 kmajor_frag(const char* tile, const KmOff& o, int ks) {
-    const bf16x4 lo = AV_DS_READ_TR16_B64((lds_b4_t)(tile + ks * 32 * 256 + o.lo));
-    const bf16x4 hi = AV_DS_READ_TR16_B64((lds_b4_t)(tile + ks * 32 * 256 + o.hi));
+    const unsigned base = (unsigned)(unsigned long long)(lds_b4_t)(tile + ks * 32 * 256);
+    const bf16x4 lo = ds_read_tr16_b64_asm(base + (unsigned)o.lo);
+    const bf16x4 hi = ds_read_tr16_b64_asm(base + (unsigned)o.hi);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -211,7 +288,7 @@ __device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const Fa
 #pragma unroll
         for (int e = 0; e < 8; ++e) m[e] = 1.f;
         if (p.drop_p > 0.f) {
-            const float ik = 1.0f / (1.0f - p.drop_p);
+            const float ik = drop_inv_keep(p.drop_p);
             if (VO || (off & 3) == 0) {                       // VO: chunks are 16-B aligned (8-element offsets) by contract
                 float m4[4];
                 drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
@@ -292,7 +369,7 @@ __device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const Fa
         }
     }
     if (p.drop_p > 0.f && p.act != AV_ACT_GELU_GF) {
-        const float ik = 1.0f / (1.0f - p.drop_p);
+        const float ik = drop_inv_keep(p.drop_p);
         if (VO || (off & 3) == 0) {
             float m4[4];
             drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
@@ -442,6 +519,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
                 if constexpr (BKM) b[j] = kmajor_frag(smem + cur * STAGE + TILE_A, bo[j], ks);
                 else b[j] = *(const bf16x8*)(bb + j * 16 * 128 + choff);
             }
+            if constexpr (AKM || BKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the asm transposed reads (kmajor_frag) are not tracked by the compiler
 #pragma unroll
             for (int i = 0; i < WM_T; ++i)
 #pragma unroll
@@ -540,7 +618,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
 #pragma unroll
             for (int e = 0; e < 8; ++e) m[e] = 1.f;
             if (p.drop_p > 0.f) {
-                const float ik = 1.0f / (1.0f - p.drop_p);
+                const float ik = drop_inv_keep(p.drop_p);
                 if ((off & 3) == 0) {
                     float m4[4];
                     drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
@@ -613,7 +691,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
             }
         }
         if (p.drop_p > 0.f && p.act != AV_ACT_GELU_GF) {        // off is a multiple of 4 whenever ldc % 4 == 0 (gn % 8 == 0)
-            const float ik = 1.0f / (1.0f - p.drop_p);
+            const float ik = drop_inv_keep(p.drop_p);
             if ((off & 3) == 0) {
                 float m4[4];
                 drop_mult4(p.drop_seed, p.drop_stream, (unsigned long long)off, p.drop_p, ik, m4);
@@ -992,8 +1070,13 @@ __device__ __forceinline__ void stage_conv2(const av_gemm_args& p, const ConvRow
     }
 }
 
-template <bool CONV>
+// KM: BOTH operands k-major (A stored [K][M], B stored [K][N]: dW = dY^T X with the tokens as K).  A half-tile slot then holds 64 k-rows x 128
+// columns (the same 16 KiB), filled by stage_kmajor<2> and read with the transposed LDS reads of kmajor_frag (two ds_read_b64_tr_b16 per
+// fragment); ring, phases, waits and epilogue are unchanged.  blockIdx.z is a K slice of k_total (split-K: av_gemm_args.k_total), the last
+// one possibly shorter and ragged (k-rows beyond it come from the zero line).
+template <bool CONV, bool KM = false>
 __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm_args p, const int nbM, const int nbN, const FastFlags fl, const int nfull, const int bm_eff) {
+    static_assert(!(CONV && KM), "k-major operands: plain products only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     AV_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;       // w in 0..7
@@ -1014,6 +1097,14 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         bid = nfull + (j >> 2);
         quad = j & 3;
     }
+    int z = blockIdx.z;
+    if constexpr (KM) {
+        // K slices ride in the 1-D grid (nfull = tiles x slices jobs): the XCD-aware remap above hands each XCD a contiguous range of
+        // (slice, tile) jobs, i.e. tiles of ONE slice that share their operand panels in that XCD's L2 (with the slices in blockIdx.z every
+        // XCD worked on all slices at once: four times the L2-miss traffic)
+        z = bid / ntile;
+        bid -= z * ntile;
+    }
     constexpr int GM = 4;
     const int per_group = GM * nbN;
     const int grp = bid / per_group, in_grp = bid - grp * per_group;
@@ -1026,7 +1117,6 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     // of one group shorten the K-tile for both.
     const int m0 = mb * bm_eff, n0 = nb * V4_BN;
     const int rows_here = p.M - m0 < bm_eff ? p.M - m0 : bm_eff;
-    const int z = blockIdx.z;
     const int zo = p.batch_inner > 0 ? z / p.batch_inner : 0;
     const int zi = p.batch_inner > 0 ? z % p.batch_inner : z;
     const bf16_t* A = (const bf16_t*)p.A + (long long)zo * p.oA + (long long)zi * p.sA;
@@ -1053,12 +1143,22 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int nk = p.K / BK;
+    int Kz = p.K;                                            // KM: this slice's share of k_total
+    if constexpr (KM) {
+        if (p.k_total > 0 && p.k_total - z * p.K < Kz) Kz = p.k_total - z * p.K;
+        nk = (Kz + BK - 1) / BK;
+    }
     ConvRows2 cr0, cr1;                                      // CONV: tap-0 pixel pointers + in-image tap masks of my rows of A0 / A1
     TapSeq ts;
     ts.seq = 0ull; ts.ntap = -1; ts.sh = 0;
     if constexpr (CONV) {
         conv_rows2_init(cr0, A, p, m0, w, lane); conv_rows2_init(cr1, A, p, m0 + 128, w, lane);
         if (p.cPM) { ts = tap_seq(p, m0, V4_BM); if (ts.ntap >= 0) nk = ts.ntap << ts.sh; }       // taps outside the image for this tile's position: skipped
+    }
+    KmLane kl[4];                                            // KM: per-lane source offsets of the four half-tile kinds (index = issue-order slot j)
+    if constexpr (KM) {
+        km_lane_init(kl[0], p.lda, m0, p.M, w, lane); km_lane_init(kl[2], p.lda, m0 + 128, p.M, w, lane);
+        km_lane_init(kl[3], p.ldb, n0, p.N, w, lane); km_lane_init(kl[1], p.ldb, n0 + 128, p.N, w, lane);
     }
     const int nh = 4 * nk;                                   // half-tiles in issue order: slot j = s & 3 : 0 = A0, 1 = B1, 2 = A1, 3 = B0
     auto issue = [&](int t, int j, int sidx) {               // half-tile 4 t + j into ring slot sidx = (4 t + j) % V4_NS; j is a compile-time constant
@@ -1067,7 +1167,17 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 #endif
         char* slot = smem + sidx * V4_HALF;
         int k0 = t * BK;
+#ifdef AV_ABL_KSCRAMBLE        // diagnostic (timing only): K-tiles in a scrambled order - no two consecutive K-tiles read adjacent lines of a row
+        k0 = (int)(((long long)t * 37) % nk) * BK;
+#endif
         if constexpr (CONV) k0 = tap_k0(p, ts, t);
+        if constexpr (KM) {
+            if (j == 0) stage_kmajor8(A, p.lda, kl[0], k0, Kz, slot, w, lane);
+            else if (j == 2) stage_kmajor8(A, p.lda, kl[2], k0, Kz, slot, w, lane);
+            else if (j == 3) stage_kmajor8(B, p.ldb, kl[3], k0, Kz, slot, w, lane);
+            else stage_kmajor8(B, p.ldb, kl[1], k0, Kz, slot, w, lane);
+            return;
+        }
         if (j == 0) { if constexpr (CONV) stage_conv2(p, cr0, k0, slot, w, lane); else stage_rows<2>(A, p.lda, m0, p.M, k0, slot, w, lane); }
         else if (j == 2) { if constexpr (CONV) stage_conv2(p, cr1, k0, slot, w, lane); else stage_rows<2>(A, p.lda, m0 + 128, p.M, k0, slot, w, lane); }
         else if (j == 3) stage_rows<2>(B, p.ldb, n0, p.N, k0, slot, w, lane);
@@ -1089,6 +1199,16 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     const int ch0 = (g ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
     const int a_row = (wr * 64 + r) * 128, b_row = (wc * 32 + r) * 128;
     bf16x8 fa[4][2], fb[2][2];
+#ifdef AV_ABL_NOREAD
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { fa[i][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; fb[i >> 1][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(fa[i][ks]), "+v"(fb[i >> 1][ks])); }
+#endif
+    bf16x8 fb0[2][2];                                        // KM: the B0 fragments of the current K-tile (phases 0 and 3)
+    Km8Base kab, kbb;                                        // KM: transposed-read bases of my A column tiles 4 wr + i / B column tiles 2 wc + j
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_b4_t)smem;
+    if constexpr (KM) { km8_base_init(kab, 1024 * wr, lane); km8_base_init(kbb, 512 * wc, lane); }
 
 // Diagnostic builds only (tools/gemm_ablate.py; never the product library): -DAV_ABL_NOMFMA keeps every LDS-DMA, fragment read, wait and
 // barrier of the main loop but issues no MFMA (the fragments are kept alive), -DAV_ABL_NODMA keeps the MFMAs and reads but stages nothing.
@@ -1101,15 +1221,38 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
 // (no per-m-tile skipping of short tiles: an `if (i < nmt)` inside these unrolled loops compiles to a scalar branch around every pair of MFMAs /
 // fragment reads - a dozen taken branches inside a 16-MFMA cluster cost more than the MFMAs they save; rows past a tile's bm_eff rows are
 // clamped re-reads of its last row, computed and never stored)
+#ifdef AV_ABL_NOREAD
+#define V4_ABL_NR 0
+#else
+#define V4_ABL_NR 4
+#endif
 #define V4_READ_A(SLOT, NMT)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
-        fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch0);                           \
-        fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch1); }
-#define V4_READ_B(SLOT)                                                                                            \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
-        fb[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                           \
-        fb[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); }
-#define V4_MMA(QA, QB)                                                                                             \
+    if constexpr (KM) {                                                                                            \
+        if (V4_ABL_NR) {                                                                                           \
+            const unsigned sb_ = lds0 + sl[SLOT] * V4_HALF;                                                        \
+            const unsigned a00_ = sb_ + kab.b[0][0], a01_ = sb_ + kab.b[0][1], a10_ = sb_ + kab.b[1][0], a11_ = sb_ + kab.b[1][1];    \
+            fa[0][0] = km8_frag<0>(a00_, a01_);          fa[0][1] = km8_frag<8192>(a00_, a01_);                    \
+            fa[1][0] = km8_frag<0>(a10_, a11_);          fa[1][1] = km8_frag<8192>(a10_, a11_);                    \
+            fa[2][0] = km8_frag<512>(a00_, a01_);        fa[2][1] = km8_frag<8192 + 512>(a00_, a01_);              \
+            fa[3][0] = km8_frag<512>(a10_, a11_);        fa[3][1] = km8_frag<8192 + 512>(a10_, a11_);              \
+        }                                                                                                          \
+    } else {                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < V4_ABL_NR; ++i) {                                                        \
+            fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch0);                       \
+            fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch1); } }
+#define V4_READ_B(SLOT, FB)                                                                                          \
+    if constexpr (KM) {                                                                                            \
+        if (V4_ABL_NR) {                                                                                           \
+            const unsigned sb_ = lds0 + sl[SLOT] * V4_HALF;                                                        \
+            const unsigned b00_ = sb_ + kbb.b[0][0], b01_ = sb_ + kbb.b[0][1], b10_ = sb_ + kbb.b[1][0], b11_ = sb_ + kbb.b[1][1];    \
+            FB[0][0] = km8_frag<0>(b00_, b01_);          FB[0][1] = km8_frag<8192>(b00_, b01_);                    \
+            FB[1][0] = km8_frag<0>(b10_, b11_);          FB[1][1] = km8_frag<8192>(b10_, b11_);                    \
+        }                                                                                                          \
+    } else {                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < V4_ABL_NR / 2; ++j) {                                                    \
+            FB[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                       \
+            FB[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); } }
+#define V4_MMA(QA, QB, FB)                                                                                            \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -1117,7 +1260,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-                V4_MFMA_OP(acc[QA][QB][i][j], fa[i][ks], fb[j][ks]);                                               \
+                V4_MFMA_OP(acc[QA][QB][i][j], fa[i][ks], FB[j][ks]);                                               \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                  \
@@ -1133,26 +1276,26 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         }
         b4 += 4; b4 = b4 >= V4_NS ? b4 - V4_NS : b4;
         // phase 0: quadrant (A0, B0)
-        V4_READ_B(3)
+        if constexpr (KM) { V4_READ_B(3, fb0) } else { V4_READ_B(3, fb) }      // k-major form: B0 stays in its own registers for phase 3 (8 fewer transposed reads per K-tile)
         __builtin_amdgcn_sched_barrier(0);
         V4_READ_A(0, nmt0)
         if (4 * t + V4_LEAD + 0 < nh) issue(t + (V4_LEAD + 0) / 4, (V4_LEAD + 0) % 4, si[0]);
-        V4_MMA(0, 0)
+        if constexpr (KM) { V4_MMA(0, 0, fb0) } else { V4_MMA(0, 0, fb) }
         // phase 1: (A0, B1)
-        V4_READ_B(1)
+        V4_READ_B(1, fb)
         if (4 * t + V4_LEAD + 1 < nh) issue(t + (V4_LEAD + 1) / 4, (V4_LEAD + 1) % 4, si[1]);
-        V4_MMA(0, 1)
+        V4_MMA(0, 1, fb)
         // phase 2: (A1, B1)
         V4_READ_A(2, nmt1)
         if (4 * t + V4_LEAD + 2 < nh) issue(t + (V4_LEAD + 2) / 4, (V4_LEAD + 2) % 4, si[2]);
-        V4_MMA(1, 1)
+        V4_MMA(1, 1, fb)
         // phase 3: (A1, B0); the K-tile's one counted wait: all of K-tile t+1 has landed, the V4_LEAD - 4 youngest half-tiles (t+2) may fly
-        V4_READ_B(3)
+        if constexpr (!KM) { V4_READ_B(3, fb) }
         if (4 * t + V4_LEAD + 3 < nh) {
             issue(t + (V4_LEAD + 3) / 4, (V4_LEAD + 3) % 4, si[3]);
             if constexpr (V4_LEAD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        V4_MMA(1, 0)
+        if constexpr (KM) { V4_MMA(1, 0, fb0) } else { V4_MMA(1, 0, fb) }
     }
 #undef V4_READ_A
 #undef V4_READ_B
@@ -1387,6 +1530,13 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         AV_STAMP7(seq, 1);
 
         bf16x8 fa[4][2], fb[2][2];
+        // Three-m-tile instantiation (222 registers): the B0 fragments keep their own 16 registers from phase 0 to phase 3 instead of being
+        // re-read (4 of the 27 ds_read_b128 of a K-tile; the four-m-tile form has no registers to spare).  -DAV_V7_KEEPB0=0: A/B builds.
+#ifndef AV_V7_KEEPB0
+#define AV_V7_KEEPB0 1
+#endif
+        constexpr bool KEEPB0 = NM1 == 3 && AV_V7_KEEPB0;
+        bf16x8 fb0[2][2];
 // Straight-line clusters: the count of m-tiles is a compile-time constant per A half (4 in half 0, NM1 in half 1).  A per-tile run-time test
 // (`if (i < nmt)`, the first form of the short-tile feature) compiled to a scalar branch around EVERY pair of MFMAs and fragment reads - a dozen
 // taken branches inside a 16-MFMA cluster that is meant to issue back to back (profiles/r04_branch_free_clusters_ab.txt: 15-20 % of the loop).
@@ -1394,11 +1544,11 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
     _Pragma("unroll") for (int i = 0; i < (N); ++i) {                                                              \
         fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 4096 + ch0);                           \
         fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 4096 + ch1); }
-#define V7_READ_B(SLOT)                                                                                            \
+#define V7_READ_B(SLOT, FB)                                                                                         \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
-        fb[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                           \
-        fb[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); }
-#define V7_MMA(QA, QB, N)                                                                                          \
+        FB[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                           \
+        FB[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); }
+#define V7_MMA(QA, QB, N, FB)                                                                                       \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -1406,7 +1556,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
         _Pragma("unroll") for (int i = 0; i < (N); ++i)                                                            \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-                acc[QA][QB][i][j] = AV_MFMA_F32_16X16X32_LP(fb[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0);     \
+                acc[QA][QB][i][j] = AV_MFMA_F32_16X16X32_LP(FB[j][ks], fa[i][ks], acc[QA][QB][i][j], 0, 0, 0);     \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                  \
@@ -1421,23 +1571,23 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
                 int y = b4 + j - 2; y = y < 0 ? y + V4_NS : y; si[j] = y;
             }
             b4 += 4; b4 = b4 >= V4_NS ? b4 - V4_NS : b4;
-            V7_READ_B(3)
+            if constexpr (KEEPB0) { V7_READ_B(3, fb0) } else { V7_READ_B(3, fb) }
             __builtin_amdgcn_sched_barrier(0);
             V7_READ_A(0, 4)
             if (4 * t + V4_LEAD + 0 < nh) issue(m0, n0, t + 2, 0, si[0]);
-            V7_MMA(0, 0, 4)
-            V7_READ_B(1)
+            if constexpr (KEEPB0) { V7_MMA(0, 0, 4, fb0) } else { V7_MMA(0, 0, 4, fb) }
+            V7_READ_B(1, fb)
             if (4 * t + V4_LEAD + 1 < nh) issue(m0, n0, t + 2, 1, si[1]);
-            V7_MMA(0, 1, 4)
+            V7_MMA(0, 1, 4, fb)
             V7_READ_A(2, NM1)
             if (4 * t + V4_LEAD + 2 < nh) issue(m0, n0, t + 2, 2, si[2]);
-            V7_MMA(1, 1, NM1)
-            V7_READ_B(3)
+            V7_MMA(1, 1, NM1, fb)
+            if constexpr (!KEEPB0) { V7_READ_B(3, fb) }
             if (4 * t + V4_LEAD + 3 < nh) {
                 issue(m0, n0, t + 2, 3, si[3]);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            V7_MMA(1, 0, NM1)
+            if constexpr (KEEPB0) { V7_MMA(1, 0, NM1, fb0) } else { V7_MMA(1, 0, NM1, fb) }
         }
 #undef V7_READ_A
 #undef V7_READ_B
@@ -1776,6 +1926,25 @@ int av_gemm_fast_try(const av_gemm_args& p, hipStream_t st) {
     const bool narrow = p.N <= 64;
     if (akm || bkm) {
         if (p.stats || p.lda % 8) return -1;
+        // dW-shaped products (both operands k-major) of at least 32 tiles of 256 x 256 (QKV, FFN; the 1024 x 1024 out-projection gradient - 16 tiles x
+        // 10+ K slices of fp32 partials - stays faster on the 128 x 128 kernel): the 8-phase kernel's k-major form, one workgroup per (tile, K slice).
+        // AVAMD_GEMM_KM8=0 keeps them all on the 128 x 128 kernel, 2 forces the 8-phase form (tests; ops.matmul_tn picks its slice count by the same rule).
+        static const int km8 = [] { const char* e = getenv("AVAMD_GEMM_KM8"); return e ? atoi(e) : 1; }();
+        if (akm && bkm && km8 && p.M >= 256 && p.N >= 256 && (km8 >= 2 || av_cdiv(p.M, V4_BM) * av_cdiv(p.N, V4_BN) >= 32) && p.batch_inner == 0 && p.lda < (1 << 24) && p.ldb < (1 << 24)) {
+            static bool km_attr = false;
+            if (!km_attr) {
+                if (hipFuncSetAttribute((const void*)gemm_nt_bf16_v4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS) != hipSuccess) {
+                    av_set_error("av_gemm(fast v4 k-major): cannot raise dynamic LDS to %d", V4_LDS);
+                    return AV_ERR_LAUNCH;
+                }
+                km_attr = true;
+            }
+            const int nbM = av_cdiv(p.M, V4_BM), nbN = av_cdiv(p.N, V4_BN);
+            hipLaunchKernelGGL((gemm_nt_bf16_v4_kernel<false, true>), dim3((unsigned)(nbM * nbN * p.batch), 1, 1), dim3(V4_NT), V4_LDS, st, p, nbM, nbN, fl,
+                               nbM * nbN * p.batch, V4_BM);
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
         if (akm && bkm) return launch_fast<128, false, true, true>(p, st, fl);
         if (akm) return launch_fast<128, false, true, false>(p, st, fl);
         return launch_fast<128, false, false, true>(p, st, fl);

@@ -647,7 +647,7 @@ extern "C" int av_cast_dropout(const void* x, int xdt, void* y, int ydt, long lo
     AV_CHECK(p >= 0.f && p < 1.f, "av_cast_dropout: p=%f out of [0,1)", p);
     if (n == 0) return AV_OK;
     if (p == 0.f) return av_cast(x, xdt, y, ydt, n, stream);
-    hipLaunchKernelGGL(cast_dropout_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, xdt, y, ydt, n, p, 1.0f / (1.0f - p), seed,
+    hipLaunchKernelGGL(cast_dropout_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, xdt, y, ydt, n, p, drop_inv_keep(p), seed,
                        stream_id);
     AV_LAUNCH_CHECK();
     return AV_OK;

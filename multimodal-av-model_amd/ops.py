@@ -213,6 +213,7 @@ def _fast_ok(t: Tensor, K: int, N: int) -> bool:
 
 # k-major operands straight into the fast GEMM (transposed LDS reads) instead of a transpose pass; AVAMD_GEMM_KMAJOR=0 = old path
 KMAJOR = os.environ.get("AVAMD_GEMM_KMAJOR", "1") != "0"
+KM8 = int(os.environ.get("AVAMD_GEMM_KM8", "1"))         # dW products of >= 32 tiles of 256 x 256 on the 8-phase kernel's k-major form (0: never, 2: from one tile on)
 # dX of a weight that changes every step: 0 (default) = transpose the weight once per version (one 12 us pass, shared by both audio passes)
 # and run the row-major 8-phase kernel; 1 = feed the k-major weight to the 128 x 128 kernel (no transpose pass)
 KMAJOR_DX_HOT = os.environ.get("AVAMD_GEMM_KMAJOR_DX", "0") != "0"
@@ -253,6 +254,22 @@ def _split_k(tiles: int, Kk: int, mn: int, slots: int = 512) -> int:
     return best
 
 
+def _split_k8(tiles: int, Kk: int, mn: int, slots: int = 256):
+    """(slices, k per slice) for the 8-phase kernel's k-major form (256 x 256 tiles, one workgroup per CU): rounds x (K-tiles x 1.55 us + 7 us of
+    prologue / epilogue) plus the partial-sum traffic (S fp32 slices written and read once)."""
+    best = (1, Kk, None)
+    for S in range(1, 33):
+        chunk = ((Kk + S - 1) // S + 63) // 64 * 64
+        if S > 1 and chunk < 512:
+            break
+        Se = (Kk + chunk - 1) // chunk
+        rounds = (tiles * Se + slots - 1) // slots
+        cost = rounds * (chunk / 64 * 1.55e-6 + 7e-6) + (Se * mn * 8 / 5e12 if Se > 1 else 0.0)
+        if best[2] is None or cost < best[2] * 0.97:
+            best = (Se, chunk, cost)
+    return best[0], best[1]
+
+
 def matmul_tn(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, alpha: float = 1.0, accumulate: bool = False) -> Tensor:
     """y[M,N] (fp32) = a[K,M]^T @ b[K,N]   (dW = dY^T X: a = dY [tokens, out], b = X [tokens, in]).
     a / b may be row-strided views (last dim contiguous)."""
@@ -268,11 +285,15 @@ def matmul_tn(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, alpha: floa
         gemm(at, bt, out, M=M, N=N, K=Kp, lda=Kp, ldb=Kp, ldc=N, alpha=alpha, R=out if accumulate else None)
         return out
     km = KMAJOR and _fast_ok(a, Kk, N) and M > 64 and M % 8 == 0 and N % 8 == 0 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    S = _split_k(tiles, Kk, M * N) if km else 1      # few output tiles, long K (tokens): split K over the batch dimension
-    if S > 1:
-        chunk = ((Kk + S - 1) // S + 63) // 64 * 64
-        S = (Kk + chunk - 1) // chunk
+    t8 = ((M + 255) // 256) * ((N + 255) // 256)
+    if km and KM8 and M >= 256 and N >= 256 and (KM8 >= 2 or t8 >= 32):         # 8-phase kernel, k-major form (gemm_fast.hip: the same conditions)
+        S, chunk = _split_k8(t8, Kk, M * N)
+    else:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        S = _split_k(tiles, Kk, M * N) if km else 1  # few output tiles, long K (tokens): split K over the batch dimension
+        if S > 1:
+            chunk = ((Kk + S - 1) // S + 63) // 64 * 64
+            S = (Kk + chunk - 1) // chunk
     if S > 1:
         parts = torch.empty((S, M, N), dtype=torch.float32, device=a.device)
         gemm(a, b, parts, M=M, N=N, K=chunk, lda=a.stride(0), ldb=b.stride(0), ldc=N, a_mode=L.A_TRANS, b_mode=L.B_KN, batch=S,

@@ -1,5 +1,8 @@
 """GPU parity of the individual HIP kernels (through the C-ABI) against plain PyTorch fp64/fp32 references."""
 import math
+import os
+import subprocess
+import sys
 
 import numpy as np
 
@@ -138,6 +141,20 @@ def test_matmul_tn_large_split_k(K, M, N):
     exp = acc + 0.5 * ref
     ops.matmul_tn(a, b, out=acc, alpha=0.5, accumulate=True)
     torch.testing.assert_close(acc, exp, **tol)
+
+
+def test_kmajor_products_on_the_forced_8_phase_form():
+    """The k-major form of the 8-phase kernel (gemm_fast.hip: gemm_nt_bf16_v4_kernel<false, true>) takes dW products of >= 32 tiles by default;
+    AVAMD_GEMM_KM8=2 (read once per process) sends every >= 256 x 256 one to it: the ragged / strided / exact-integer cases above again in
+    a child process under that switch."""
+    if os.environ.get("AVAMD_GEMM_KM8") == "2":
+        pytest.skip("already the forced run")
+    env = dict(os.environ, AVAMD_GEMM_KM8="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
+                        "test_fast_gemm_kmajor_operands or test_matmul_tn_large_split_k or test_matmul_nn_tn"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -360,7 +377,8 @@ def test_conv3d_front_fast_kernel():
     torch.testing.assert_close(stats[:, 1].sum(0), (ref * ref).sum(0), rtol=2e-3, atol=0.5)
 
 
-@pytest.mark.parametrize("Kk,M,N", [(100, 136, 200), (64, 128, 128), (777, 264, 72), (6368, 1024, 1024), (199, 4096, 1024)])
+@pytest.mark.parametrize("Kk,M,N", [(100, 136, 200), (64, 128, 128), (777, 264, 72), (6368, 1024, 1024), (199, 4096, 1024), (777, 264, 520),
+                                     (1300, 1000, 264), (12736, 520, 1024)])
 def test_fast_gemm_kmajor_operands(Kk, M, N):
     """k-major operands read through ds_read_b64_tr_b16 (dW = dY^T X with both operands [tokens][features], dX = dY W with
     W [out][in]): ragged K, ragged tiles, row-strided views, and an exact integer check that would expose a transposed tile."""
