@@ -139,11 +139,17 @@ __device__ __forceinline__ bf16x4 ds_read_tr16_b64_imm(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
     return v;
 }
+// The two halves of a fragment stay SEPARATE values until the wait that retires the reads: the compiler takes an asm result as ready at once,
+// so a join (register copies into one 4-register MFMA operand) placed between the read and the wait would copy stale registers.  The kernel
+// ties the halves to its wait (km8_tie*: empty asm with the halves as in/out operands) and joins them after it.
 template <int IMM>
-__device__ __forceinline__ bf16x8 km8_frag(unsigned lo_addr, unsigned hi_addr) {
-    const bf16x4 lo = ds_read_tr16_b64_imm<IMM>(lo_addr), hi = ds_read_tr16_b64_imm<IMM>(hi_addr);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+__device__ __forceinline__ void km8_read(unsigned lo_addr, unsigned hi_addr, bf16x4 (&d)[2]) {
+    d[0] = ds_read_tr16_b64_imm<IMM>(lo_addr); d[1] = ds_read_tr16_b64_imm<IMM>(hi_addr);
 }
+__device__ __forceinline__ void km8_tie8(bf16x4 (&f)[2][2][2]) {     // [tile][k-step][half]
+    asm volatile("" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+}
+__device__ __forceinline__ bf16x8 km8_join(const bf16x4 (&d)[2]) { return __builtin_shufflevector(d[0], d[1], 0, 1, 2, 3, 4, 5, 6, 7); }
 
 // per-lane byte offsets (inside a k-major tile, k-step 0) of the two transposed reads of column tile `ct`
 struct KmOff { int lo, hi; };
@@ -167,11 +173,15 @@ __device__ __forceinline__ bf16x4 ds_read_tr16_b64_asm(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
-__device__ __forceinline__ bf16x8 kmajor_frag(const char* tile, const KmOff& o, int ks) {
+// (the two halves of a fragment stay separate values until the caller's wait: kmajor_tie4 carries them through it as in/out operands, so the
+// register copies that join them into one MFMA operand cannot be scheduled before the data has arrived)
+__device__ __forceinline__ void kmajor_read(const char* tile, const KmOff& o, int ks, bf16x4 (&d)[2]) {
     const unsigned base = (unsigned)(unsigned long long)(lds_b4_t)(tile + ks * 32 * 256);
-    const bf16x4 lo = ds_read_tr16_b64_asm(base + (unsigned)o.lo);
-    const bf16x4 hi = ds_read_tr16_b64_asm(base + (unsigned)o.hi);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    d[0] = ds_read_tr16_b64_asm(base + (unsigned)o.lo);
+    d[1] = ds_read_tr16_b64_asm(base + (unsigned)o.hi);
+}
+__device__ __forceinline__ void kmajor_tie4(bf16x4 (&f)[4][2]) {
+    asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1]));
 }
 
 // Position-major pixel order (av_gemm_args.cNF / cPM): decode an output row and address an input pixel.
@@ -509,17 +519,31 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_bf16_kernel(const av_gemm_args 
         for (int ks = 0; ks < 2; ++ks) {
             const int choff = ((ks * 4 + g) ^ sw) << 4;
             bf16x8 a[WM_T], b[4];
+            bf16x4 ah[4][2], bh[4][2];                           // halves of the k-major fragments until the wait below
 #pragma unroll
             for (int i = 0; i < WM_T; ++i) {
-                if constexpr (AKM) a[i] = kmajor_frag(smem + cur * STAGE, ao[i], ks);
+                if constexpr (AKM) kmajor_read(smem + cur * STAGE, ao[i], ks, ah[i]);
                 else a[i] = *(const bf16x8*)(ab + i * 16 * 128 + choff);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (BKM) b[j] = kmajor_frag(smem + cur * STAGE + TILE_A, bo[j], ks);
+                if constexpr (BKM) kmajor_read(smem + cur * STAGE + TILE_A, bo[j], ks, bh[j]);
                 else b[j] = *(const bf16x8*)(bb + j * 16 * 128 + choff);
             }
-            if constexpr (AKM || BKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the asm transposed reads (kmajor_frag) are not tracked by the compiler
+            if constexpr (AKM || BKM) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 // the asm transposed reads are not tracked by the compiler
+                if constexpr (AKM) {
+                    static_assert(WM_T == 4, "k-major A: 128-wide tiles");
+                    kmajor_tie4(ah);
+#pragma unroll
+                    for (int i = 0; i < WM_T; ++i) a[i] = __builtin_shufflevector(ah[i][0], ah[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                if constexpr (BKM) {
+                    kmajor_tie4(bh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[j] = __builtin_shufflevector(bh[j][0], bh[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < WM_T; ++i)
 #pragma unroll
@@ -1206,6 +1230,7 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         for (int ks = 0; ks < 2; ++ks) { fa[i][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; fb[i >> 1][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(fa[i][ks]), "+v"(fb[i >> 1][ks])); }
 #endif
     bf16x8 fb0[2][2];                                        // KM: the B0 fragments of the current K-tile (phases 0 and 3)
+    bf16x4 kfa[2][2][2][2], kfb[2][2][2];                    // KM: halves of the fragments in flight: [m-tile pair][parity][k-step][half], [n-tile][k-step][half]
     Km8Base kab, kbb;                                        // KM: transposed-read bases of my A column tiles 4 wr + i / B column tiles 2 wc + j
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_b4_t)smem;
     if constexpr (KM) { km8_base_init(kab, 1024 * wr, lane); km8_base_init(kbb, 512 * wc, lane); }
@@ -1231,30 +1256,40 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         if (V4_ABL_NR) {                                                                                           \
             const unsigned sb_ = lds0 + sl[SLOT] * V4_HALF;                                                        \
             const unsigned a00_ = sb_ + kab.b[0][0], a01_ = sb_ + kab.b[0][1], a10_ = sb_ + kab.b[1][0], a11_ = sb_ + kab.b[1][1];    \
-            fa[0][0] = km8_frag<0>(a00_, a01_);          fa[0][1] = km8_frag<8192>(a00_, a01_);                    \
-            fa[1][0] = km8_frag<0>(a10_, a11_);          fa[1][1] = km8_frag<8192>(a10_, a11_);                    \
-            fa[2][0] = km8_frag<512>(a00_, a01_);        fa[2][1] = km8_frag<8192 + 512>(a00_, a01_);              \
-            fa[3][0] = km8_frag<512>(a10_, a11_);        fa[3][1] = km8_frag<8192 + 512>(a10_, a11_);              \
+            km8_read<0>(a00_, a01_, kfa[0][0][0]);       km8_read<8192>(a00_, a01_, kfa[0][0][1]);                 \
+            km8_read<0>(a10_, a11_, kfa[0][1][0]);       km8_read<8192>(a10_, a11_, kfa[0][1][1]);                 \
+            km8_read<512>(a00_, a01_, kfa[1][0][0]);     km8_read<8192 + 512>(a00_, a01_, kfa[1][0][1]);           \
+            km8_read<512>(a10_, a11_, kfa[1][1][0]);     km8_read<8192 + 512>(a10_, a11_, kfa[1][1][1]);           \
         }                                                                                                          \
     } else {                                                                                                       \
     _Pragma("unroll") for (int i = 0; i < V4_ABL_NR; ++i) {                                                        \
             fa[i][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch0);                       \
             fa[i][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + a_row + i * 2048 + ch1); } }
-#define V4_READ_B(SLOT, FB)                                                                                          \
+#define V4_READ_B(SLOT, FB, KFB)                                                                                   \
     if constexpr (KM) {                                                                                            \
         if (V4_ABL_NR) {                                                                                           \
             const unsigned sb_ = lds0 + sl[SLOT] * V4_HALF;                                                        \
             const unsigned b00_ = sb_ + kbb.b[0][0], b01_ = sb_ + kbb.b[0][1], b10_ = sb_ + kbb.b[1][0], b11_ = sb_ + kbb.b[1][1];    \
-            FB[0][0] = km8_frag<0>(b00_, b01_);          FB[0][1] = km8_frag<8192>(b00_, b01_);                    \
-            FB[1][0] = km8_frag<0>(b10_, b11_);          FB[1][1] = km8_frag<8192>(b10_, b11_);                    \
+            km8_read<0>(b00_, b01_, KFB[0][0]);          km8_read<8192>(b00_, b01_, KFB[0][1]);                    \
+            km8_read<0>(b10_, b11_, KFB[1][0]);          km8_read<8192>(b10_, b11_, KFB[1][1]);                    \
         }                                                                                                          \
     } else {                                                                                                       \
     _Pragma("unroll") for (int j = 0; j < V4_ABL_NR / 2; ++j) {                                                    \
             FB[j][0] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch0);                       \
             FB[j][1] = *(const bf16x8*)(smem + sl[SLOT] * V4_HALF + b_row + j * 2048 + ch1); } }
-#define V4_MMA(QA, QB, FB)                                                                                            \
+#define V4_JOIN_A                                                                                                  \
+    if constexpr (KM) { if (V4_ABL_NR) {                                                                           \
+        km8_tie8(kfa[0]); km8_tie8(kfa[1]);                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { fa[i][0] = km8_join(kfa[i >> 1][i & 1][0]); fa[i][1] = km8_join(kfa[i >> 1][i & 1][1]); } } }
+#define V4_JOIN_B(FB, KFB)                                                                                         \
+    if constexpr (KM) { if (V4_ABL_NR) {                                                                           \
+        km8_tie8(KFB);                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) { FB[j][0] = km8_join(KFB[j][0]); FB[j][1] = km8_join(KFB[j][1]); } } }
+#define V4_JOIN_NONE
+#define V4_MMA(QA, QB, FB, JOIN)                                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+    JOIN                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
@@ -1276,30 +1311,33 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         }
         b4 += 4; b4 = b4 >= V4_NS ? b4 - V4_NS : b4;
         // phase 0: quadrant (A0, B0)
-        if constexpr (KM) { V4_READ_B(3, fb0) } else { V4_READ_B(3, fb) }      // k-major form: B0 stays in its own registers for phase 3 (8 fewer transposed reads per K-tile)
+        if constexpr (KM) { V4_READ_B(3, fb0, kfb) } else { V4_READ_B(3, fb, kfb) }      // k-major form: B0 stays in its own registers for phase 3 (8 fewer transposed reads per K-tile)
         __builtin_amdgcn_sched_barrier(0);
         V4_READ_A(0, nmt0)
         if (4 * t + V4_LEAD + 0 < nh) issue(t + (V4_LEAD + 0) / 4, (V4_LEAD + 0) % 4, si[0]);
-        if constexpr (KM) { V4_MMA(0, 0, fb0) } else { V4_MMA(0, 0, fb) }
+        if constexpr (KM) { V4_MMA(0, 0, fb0, V4_JOIN_A V4_JOIN_B(fb0, kfb)) } else { V4_MMA(0, 0, fb, V4_JOIN_NONE) }
         // phase 1: (A0, B1)
-        V4_READ_B(1, fb)
+        V4_READ_B(1, fb, kfb)
         if (4 * t + V4_LEAD + 1 < nh) issue(t + (V4_LEAD + 1) / 4, (V4_LEAD + 1) % 4, si[1]);
-        V4_MMA(0, 1, fb)
+        V4_MMA(0, 1, fb, V4_JOIN_B(fb, kfb))
         // phase 2: (A1, B1)
         V4_READ_A(2, nmt1)
         if (4 * t + V4_LEAD + 2 < nh) issue(t + (V4_LEAD + 2) / 4, (V4_LEAD + 2) % 4, si[2]);
-        V4_MMA(1, 1, fb)
+        V4_MMA(1, 1, fb, V4_JOIN_A)
         // phase 3: (A1, B0); the K-tile's one counted wait: all of K-tile t+1 has landed, the V4_LEAD - 4 youngest half-tiles (t+2) may fly
-        if constexpr (!KM) { V4_READ_B(3, fb) }
+        if constexpr (!KM) { V4_READ_B(3, fb, kfb) }
         if (4 * t + V4_LEAD + 3 < nh) {
             issue(t + (V4_LEAD + 3) / 4, (V4_LEAD + 3) % 4, si[3]);
             if constexpr (V4_LEAD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (KM) { V4_MMA(1, 0, fb0) } else { V4_MMA(1, 0, fb) }
+        if constexpr (KM) { V4_MMA(1, 0, fb0, V4_JOIN_NONE) } else { V4_MMA(1, 0, fb, V4_JOIN_B(fb, kfb)) }
     }
 #undef V4_READ_A
 #undef V4_READ_B
 #undef V4_MMA
+#undef V4_JOIN_A
+#undef V4_JOIN_B
+#undef V4_JOIN_NONE
 #undef V4_MFMA_OP
     if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the entry barrier of wavefronts 4-7
     AV_STAMP(2);

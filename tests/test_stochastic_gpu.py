@@ -16,7 +16,11 @@ def _mask(n, p, seed, stream):
     L = pkg("_lib"); ops = pkg("ops")
     u = torch.empty(n, device="cuda")
     L.check(L.lib().av_dropout_uniform(ops.ptr(u), n, seed, stream, ops.stream()))
-    return (u >= p).float() / (1.0 - p), u
+    # survivors are scaled by the inverse of the REALISED keep fraction: the keep test resolves p to ceil(65536 p) sixteen-bit steps
+    # (av_common.h: drop_inv_keep), evaluated in fp32 like the kernels do
+    thr = np.ceil(np.float32(p) * np.float32(65536.0))
+    inv = float(np.float32(65536.0) / (np.float32(65536.0) - np.float32(thr)))
+    return (u >= p).float() * inv, u
 
 
 def test_dropout_kernel_statistics_and_determinism():
