@@ -1080,11 +1080,22 @@ __device__ __forceinline__ void conv_rows2_init(ConvRows2& cr, const bf16_t* __r
         }
     }
 }
-__device__ __forceinline__ void stage_conv2(const av_gemm_args& p, const ConvRows2& cr, int k0, char* tile, int w, int lane) {
+// all_in: every row of the tile is a real pixel whose window contains this tap (a position-major tile after tap_seq dropped the taps outside the
+// image for its position): no per-lane select in front of the LDS-DMA - in the staggered schedule the instructions between a phase's fragment
+// reads and its barrier are on the critical path (see stage_kmajor8)
+__device__ __forceinline__ void stage_conv2(const av_gemm_args& p, const ConvRows2& cr, int k0, char* tile, int w, int lane, bool all_in) {
     const int sub = lane >> 3, pch = lane & 7;
     const int tap = k0 / p.cCin, c0 = k0 - tap * p.cCin;
     const int ky = tap / p.cKw, kx = tap - ky * p.cKw;
     const long long toff = ((long long)ky * p.cW + kx) * ((p.cPM & 1) ? p.cNF : 1) * p.cCtot + c0;          // wave-uniform
+    if (all_in) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)((w * 2 + i) * 1024));
+            __builtin_amdgcn_global_load_lds((gptr_t)(cr.rowp[i] + toff), (lptr_t)(tile + off), 16, 0, 0);
+        }
+        return;
+    }
     const bf16_t* zl = (const bf16_t*)g_zero_line + ((pch ^ sub) << 3);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1179,6 +1190,8 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
         conv_rows2_init(cr0, A, p, m0, w, lane); conv_rows2_init(cr1, A, p, m0 + 128, w, lane);
         if (p.cPM) { ts = tap_seq(p, m0, V4_BM); if (ts.ntap >= 0) nk = ts.ntap << ts.sh; }       // taps outside the image for this tile's position: skipped
     }
+    // CONV: a whole tile of real rows at ONE output position whose out-of-image taps were dropped above => every staged row is in the image
+    const bool conv_all_in = CONV && (p.cPM & 2) && ts.ntap >= 0 && m0 + V4_BM <= p.M && m0 / p.cNF == (m0 + V4_BM - 1) / p.cNF;
     KmLane kl[4];                                            // KM: per-lane source offsets of the four half-tile kinds (index = issue-order slot j)
     if constexpr (KM) {
         km_lane_init(kl[0], p.lda, m0, p.M, w, lane); km_lane_init(kl[2], p.lda, m0 + 128, p.M, w, lane);
@@ -1202,8 +1215,8 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v4_kernel(const av_gemm
             else stage_kmajor8(B, p.ldb, kl[1], k0, Kz, slot, w, lane);
             return;
         }
-        if (j == 0) { if constexpr (CONV) stage_conv2(p, cr0, k0, slot, w, lane); else stage_rows<2>(A, p.lda, m0, p.M, k0, slot, w, lane); }
-        else if (j == 2) { if constexpr (CONV) stage_conv2(p, cr1, k0, slot, w, lane); else stage_rows<2>(A, p.lda, m0 + 128, p.M, k0, slot, w, lane); }
+        if (j == 0) { if constexpr (CONV) stage_conv2(p, cr0, k0, slot, w, lane, conv_all_in); else stage_rows<2>(A, p.lda, m0, p.M, k0, slot, w, lane); }
+        else if (j == 2) { if constexpr (CONV) stage_conv2(p, cr1, k0, slot, w, lane, conv_all_in); else stage_rows<2>(A, p.lda, m0 + 128, p.M, k0, slot, w, lane); }
         else if (j == 3) stage_rows<2>(B, p.ldb, n0, p.N, k0, slot, w, lane);
         else stage_rows<2>(B, p.ldb, n0 + 128, p.N, k0, slot, w, lane);
     };
