@@ -1461,6 +1461,21 @@ __device__ __forceinline__ void v7_stage_b(const bf16_t* __restrict__ base, long
     }
 }
 
+// s_waitcnt vmcnt(8 + S) for a run-time, wave-uniform S in 0..32 (rounded DOWN to an even number: a smaller count waits longer, never shorter).
+// Loads, stores and LDS-DMA share ONE in-order counter: after a tile's epilogue the S youngest entries are its stores, behind them the 8
+// LDS-DMA instructions of the next tile's K-tile 1, behind those the 8 of K-tile 0.  `vmcnt(8)` at the next tile's start therefore also waited
+// for all but 8 of the STORES (6.7 us per tile boundary in the FFN-up product with two outputs, profiles/r04_v7_stamps.txt); with the store
+// count in the immediate the stores drain under K-tiles 0 and 1 (K-tile 2's data is younger than they are: its wait retires them).
+__device__ __forceinline__ void v7_wait_dma8_plus(int S) {
+#define V7_WCASE(H) case H: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + 2 * (H)) : "memory"); break;
+    switch (S >> 1) {
+        V7_WCASE(16) V7_WCASE(15) V7_WCASE(14) V7_WCASE(13) V7_WCASE(12) V7_WCASE(11) V7_WCASE(10) V7_WCASE(9) V7_WCASE(8) V7_WCASE(7) V7_WCASE(6)
+        V7_WCASE(5) V7_WCASE(4) V7_WCASE(3) V7_WCASE(2) V7_WCASE(1)
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+#undef V7_WCASE
+}
+
 // one 8-column chunk of a lane: c0 / c1 = the accumulators of n-tiles j = 0 / 1 (columns gn .. gn + 3 / gn + 4 .. gn + 7 of row gm)
 template <bool VO>
 __device__ __forceinline__ void v7_chunk(const av_gemm_args& p, const FastFlags& fl, const f32x4& c0, const f32x4& c1, const float (&bv)[8],
@@ -1544,12 +1559,15 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
 
     int li = slot;
     int m0 = 0, n0 = 0, mb = 0;
-    float bnext = 0.f;                                       // bias (my lane's column) of the tile whose ring prefetch is in flight (loop-carried)
-        if (li < cn) {
+    float bnext = 0.f;                                       // bias (my lane's column) of the tile about to start (loop-carried)
+    if (li < cn) {
         coords(cs + li, m0, n0, mb);
+        bnext = load_bias(n0);                               // BEFORE the prefetch: the consume below then needs the load only (the 16 LDS-DMA are younger)
         prefetch(m0, n0);
-        bnext = load_bias(n0);
+        asm volatile("" : "+v"(bnext));                      // no load is pending in a loop-carried register (the compiler would wait vmcnt(0) at its every use)
     }
+    int pend = 0;                                            // stores of the previous tile's epilogue that may still be in flight (a lower bound of their count)
+    static const bool v7_decouple = true;
     int seq = 0;                                             // (diagnostic stamps only)
     while (li < cn) {
         AV_STAMP7(seq, 0);
@@ -1569,16 +1587,17 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // K-tile 0 (the 8 oldest LDS-DMA instructions of this tile; anything older - the previous tile's stores - has completed too)
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // the bias loads of this tile were issued with its prefetch: consume them HERE (the compiler's wait for them lands beside the wait
-        // above, not in the epilogue behind the next tile's just-issued LDS-DMA)
-        asm volatile("" : "+v"(bnext));
+        // K-tile 0: the 8 oldest LDS-DMA instructions of this tile; K-tile 1's eight and the previous tile's stores may stay in flight
+        if (nk > 1) v7_wait_dma8_plus(pend); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this tile's bias was loaded at the START of the previous tile (first tile: in the prologue) and consumed at the end of its main loop:
+        // a consume HERE would make the compiler wait for everything in flight, i.e. for the previous tile's stores
         const float bcur = bnext;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (wr == 1) __builtin_amdgcn_s_barrier();           // wavefronts 4-7 run one barrier behind
         AV_STAMP7(seq, 1);
+        float bload = 0.f;
+        if (has_next) bload = load_bias(nn0);                // next tile's bias: in flight under this tile's main loop
 
         bf16x8 fa[4][2], fb[2][2];
         // Three-m-tile instantiation (222 registers): the B0 fragments keep their own 16 registers from phase 0 to phase 3 instead of being
@@ -1636,7 +1655,9 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
             if constexpr (!KEEPB0) { V7_READ_B(3, fb) }
             if (4 * t + V4_LEAD + 3 < nh) {
                 issue(m0, n0, t + 2, 3, si[3]);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                // all of K-tile t + 1 has landed.  In K-tile 0 that data is OLDER than the previous tile's stores (it was requested before
+                // them): they may stay in flight; from K-tile 1 on the awaited data is younger than the stores and the wait retires them
+                if (t == 0 && pend > 0) v7_wait_dma8_plus(pend); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (KEEPB0) { V7_MMA(1, 0, NM1, fb0) } else { V7_MMA(1, 0, NM1, fb) }
         }
@@ -1648,8 +1669,23 @@ __global__ __launch_bounds__(V4_NT, 2) void gemm_nt_bf16_v7_kernel(const av_gemm
         AV_STAMP7(seq, 2);
 
         // the ring is free: request the next tile's first two K-tiles, then store this tile from the registers
-        if (has_next) { prefetch(nm0, nn0); bnext = load_bias(nn0); }
+        asm volatile("" : "+v"(bload));                      // next tile's bias (requested a main loop ago): nothing else of mine is in flight here
+        bnext = bload;
+        if (has_next) prefetch(nm0, nn0);
         const int m_end = m0 + rows_here;
+        {
+            // stores this wavefront is about to issue, counted conservatively: a chunk (16 rows x 64 columns of the wavefront) stores iff its first
+            // row and first column are inside the tile; per chunk one 16-B store per bf16 output, two per fp32 output
+            int na = 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) na += (m0 + a * 128 + (2 * i + wr) * 16 < m_end) ? 1 : 0;
+            const int nb = (n0 + wc * 64 < p.N ? 1 : 0) + (n0 + wc * 64 + 32 < p.N ? 1 : 0);
+            const int spc = (p.out_dtype == AV_F32 ? 2 : 1) * (p.C2 ? 2 : 1);
+            pend = v7_decouple ? __builtin_amdgcn_readfirstlane(na * nb * spc) : 0;
+            if (pend > 32) pend = 32;
+        }
         float bv[8], bo[8];                                  // bias of my columns of B half 0 / 1 (rolled form: the two windows swap)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bv[e] = __shfl(bcur, g * 8 + e, 64); bo[e] = __shfl(bcur, 32 + g * 8 + e, 64); }
