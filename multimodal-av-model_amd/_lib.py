@@ -7,6 +7,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+from . import precision as _precision
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AVAMD_LIB") or os.path.join(_HERE, "libavhip.so")      # AVAMD_LIB: another build of the same library (A/B tooling)
 
@@ -113,11 +115,11 @@ SIGNATURES = {
 _RESTYPES = {"av_last_error": C.c_char_p}
 
 _libs = {}
+_by_mode = {}                      # precision mode -> loaded library: lib() runs once per kernel launch (a dict hit, not a path computation)
 
 
 def _path() -> str:
-    from . import precision
-    if precision.get_precision() == "fp16":
+    if _precision.get_precision() == "fp16":
         return os.environ.get("AVAMD_LIB_F16") or os.path.join(_HERE, "libavhip_f16.so")
     return LIB_PATH
 
@@ -125,6 +127,9 @@ def _path() -> str:
 def lib() -> C.CDLL:
     """Load (once per library) and return the HIP library of the current precision mode (fp32 / bf16: libavhip.so, fp16: libavhip_f16.so);
     raise if it is missing - no fallback exists."""
+    l = _by_mode.get(_precision._mode)
+    if l is not None:
+        return l
     path = _path()
     l = _libs.get(path)
     if l is None:
@@ -142,6 +147,7 @@ def lib() -> C.CDLL:
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, C.c_int)
         _libs[path] = l
+    _by_mode[_precision._mode] = l
     return l
 
 
