@@ -1,5 +1,5 @@
 # the other BASELINE configs on one box (parity-test sizes, not bench lines): as executed / deterministic; config 5 also under the GradScaler law
-for args in "--batch 2 --seconds 1" "--batch 32" "--batch 8 --seconds 15" "--batch 128 --steps 10 --warmup 3" "--batch 128 --steps 10 --warmup 3 --loss-scaling"; do
+for args in "--batch 2 --seconds 1" "--batch 32" "--batch 8 --seconds 15" "--batch 128 --steps 10 --warmup 3" "--batch 128 --steps 10 --warmup 3 --loss-scaling" "--batch 128 --steps 10 --warmup 3 --loss-scaling --precision fp16"; do
   timeout -k 10 400 python bench.py $args --no-cpu-baseline --no-probe 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
