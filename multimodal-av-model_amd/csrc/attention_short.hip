@@ -220,9 +220,19 @@ __device__ __forceinline__ void dma_rows8(bf16_t* img, const bf16_t* __restrict_
     __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)((char*)img + grp * 1024), 16, 0, 0);
 }
 
+// Diagnostic builds only (-DAV_ATTN_STAMPS, tools/attn_stamps.py; never the product library): s_memrealtime (100 MHz) per workgroup at entry /
+// operands landed / end of the arithmetic of wavefront 0's first query tile / exit
+#ifdef AV_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[4096 * 4];
+#define AV_ASTAMP(SLOT) do { if (threadIdx.x == 0) { const unsigned bid_ = blockIdx.y * gridDim.x + blockIdx.x; if (bid_ < 4096) g_attn_stamps[bid_ * 4 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define AV_ASTAMP(SLOT) do { } while (0)
+#endif
+
 template <int NKP, int DROP>
 __global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    AV_ASTAMP(0);
     bf16_t* Ks = (bf16_t*)smem;
     bf16_t* Vs = Ks + NKP * 32 * 64;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
@@ -257,12 +267,14 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    AV_ASTAMP(1);
 
     const float c = p.scale * LOG2E;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int qt = w + NW * i;
         if (qt >= nqt) break;                                   // wave-uniform
+        if (i == 1) AV_ASTAMP(2);
         asm volatile("" ::: "memory");                          // keep the LDS fragment reads of the two tiles apart (no cross-tile hoisting: spills)
         const int qrow = qt * 16 + r;
         f32x4 S[2 * NKP];
@@ -344,6 +356,10 @@ __global__ __launch_bounds__(NT, 4) void attn_fwd_short2_kernel(const AttnP p) {
             if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Tq + qrow] = (mx * c + __builtin_amdgcn_logf(sum)) * LN2;
         }
     }
+#ifdef AV_ATTN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // diagnostic: the exit stamp includes the completion of this wavefront's stores
+#endif
+    AV_ASTAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------------- forward, T > 256
@@ -920,6 +936,12 @@ int launch_bwd_short(const BwdP& p, int R, int lds, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef AV_ATTN_STAMPS
+extern "C" int av_attn_stamps_read(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : 1;
+}
+#endif
 
 template <bool DROP>
 int launch_fwd_long(const AttnP& p, hipStream_t st) {
