@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
                                                          long long rows_per_block, bf16_t* __restrict__ dxl, float drop_p,
                                                          unsigned long long drop_seed, unsigned drop_stream) {
     constexpr int cols = NV * 256;
-    const float drop_ik = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const float drop_ik = drop_p > 0.f ? drop_inv_keep(drop_p) : 1.0f;     // the forward site scaled its survivors by the same factor
     __shared__ float red[4][2][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
