@@ -285,6 +285,12 @@ struct FastFlags { int c_vec, r_vec, aux_vec; };
 // shared tail of the coalesced epilogue: optional pre-activation copy, activation, dropout, residual, store (8 columns)
 // VO ("vector only", v7's specialised instantiations): the caller guarantees whole, 16-B aligned chunks for C / C2 / R / aux (N % 8 == 0 and the
 // FastFlags all set), so the element-wise fallbacks are not generated
+// The second output of the FFN-up product (the saved gradient factor) is read again only in the backward: it takes the non-temporal store path and
+// does not evict operand panels from L2 (+0.6 % on the step; non-temporal LOADS of the saved factor / the fp32 residual were 10-20 % slower -
+// those operands are cache hits; profiles/r04_nontemporal_ab.txt).  -DAV_EPI_NT=0: A/B builds.
+#ifndef AV_EPI_NT
+#define AV_EPI_NT 1
+#endif
 template <bool VO>
 __device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const FastFlags& fl0, float (&v)[8], long long off, int gm, int gn, bool full0,
                                                  const float* R) {
@@ -329,7 +335,13 @@ __device__ __forceinline__ void epilogue_store_t(const av_gemm_args& p, const Fa
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)gf[e];
-                *(bf16x8*)((bf16_t*)p.C2 + off) = o;
+                {
+#if AV_EPI_NT        // the gradient factor is read again only in the backward: non-temporal store (it does not push operand panels out of L2)
+                    __builtin_nontemporal_store(o, (bf16x8*)((bf16_t*)p.C2 + off));
+#else
+                    *(bf16x8*)((bf16_t*)p.C2 + off) = o;
+#endif
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (gn + e < p.N) st_any(p.C2, off + e, p.out_dtype, gf[e]);
