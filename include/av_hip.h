@@ -336,6 +336,36 @@ int av_wav_read_mono_f32(const char* path, long long frame0, long long n, float*
 int av_resample_sinc(const float* x, long long n_in, float* y, long long n_out, const float* win, const float* delta, int nwin, int num_table,
                      int sr_in, int sr_out, void* stream);
 
+/* ---- one wav2vec2 encoder layer, forward, as ONE call ------------------------------------------------------------------------------------
+ * replaces: Wav2Vec2EncoderLayerStableLayerNorm.forward (hf:611-640: layer_norm -> attention (hf:438-463: q/k/v projections, softmax(QK^T)V with
+ * probability dropout, out_proj) -> hidden dropout -> + residual -> final_layer_norm -> feed_forward (hf:565-572: intermediate_dense, GELU,
+ * activation dropout, output_dense, hidden dropout) -> + residual), 16-bit compute type, fp32 residual stream.
+ * The entry point enqueues the same seven kernels with the same arguments as av_layernorm_fwd / av_gemm / av_attention_fwd_mask called one by one
+ * (bit-identical results); it exists because at small batches the step is bound by host round trips, not by the device.
+ * Buffers (caller-allocated, M = B * T rows): h [M][hidden] fp32 in; x1, x2 [M][hidden], qkv [M][3 hidden] (= [B][T][3][heads][hidden / heads]),
+ * ao [M][hidden], g [M][inter], u [M][inter] (optional: the pre-activation, or with gf != 0 the saved gradient factor gelu'(.) o mask / keep)
+ * in the 16-bit type; h2, h3 [M][hidden] fp32; mu1 / rs1 / mu2 / rs2 [M] and lse [B][heads][T] fp32 (optional: saved for the backward).
+ * Weights in nn.Linear layout in the 16-bit type (w_qkv = the packed [3 hidden][hidden] q / k / v projection), biases and LayerNorm parameters fp32.
+ * Dropout masks: the counter-hash streams stream_base + 0 (after out_proj), + 1 (after GELU), + 2 (after output_dense), + 3 (attention
+ * probabilities; amask = optional precomputed keep bits of av_attention_dropmask) under `seed`; a probability of 0 disables a site. */
+typedef struct av_w2v2_layer_args {
+    int B, T, hidden, heads, inter;
+    int lp;                      /* dtype code of the 16-bit tensors (AV_BF16 = "the library's 16-bit type") */
+    int gf;                      /* != 0: FFN-up runs AV_ACT_GELU_GF (u receives the gradient factor) instead of AV_ACT_GELU (u receives the pre-activation) */
+    int stream_base;
+    float eps, scale;            /* LayerNorm epsilon; softmax scale (head_dim^-0.5) */
+    float hd_p, at_p, ac_p;      /* hidden / attention / activation dropout probabilities */
+    unsigned long long seed;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *b_qkv, *b_o, *b_1, *b_2;
+    const void *w_qkv, *w_o, *w_1, *w_2;
+    const float* h;
+    const int* klen;             /* [B] valid key counts or NULL */
+    const void* amask;           /* optional keep bits for the attention probabilities */
+    void *x1, *qkv, *ao, *x2, *u, *g;
+    float *mu1, *rs1, *lse, *h2, *mu2, *rs2, *h3;
+} av_w2v2_layer_args;
+int av_w2v2_layer_fwd(const av_w2v2_layer_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,11 +38,25 @@ class GemmArgs(C.Structure):
     ]
 
 
+class W2v2LayerArgs(C.Structure):
+    _fields_ = [
+        ("B", i32), ("T", i32), ("hidden", i32), ("heads", i32), ("inter", i32), ("lp", i32), ("gf", i32), ("stream_base", i32),
+        ("eps", f32), ("scale", f32), ("hd_p", f32), ("at_p", f32), ("ac_p", f32),
+        ("seed", C.c_ulonglong),
+        ("ln1_g", vp), ("ln1_b", vp), ("ln2_g", vp), ("ln2_b", vp), ("b_qkv", vp), ("b_o", vp), ("b_1", vp), ("b_2", vp),
+        ("w_qkv", vp), ("w_o", vp), ("w_1", vp), ("w_2", vp),
+        ("h", vp), ("klen", vp), ("amask", vp),
+        ("x1", vp), ("qkv", vp), ("ao", vp), ("x2", vp), ("u", vp), ("g", vp),
+        ("mu1", vp), ("rs1", vp), ("lse", vp), ("h2", vp), ("mu2", vp), ("rs2", vp), ("h3", vp),
+    ]
+
+
 # name -> argtypes (restype is int status unless listed in _RESTYPES); must list every symbol of include/av_hip.h
 SIGNATURES = {
     "av_last_error": [],
     "av_version": [],
     "av_gemm": [C.POINTER(GemmArgs), vp],
+    "av_w2v2_layer_fwd": [C.POINTER(W2v2LayerArgs), vp],
     "av_transpose": [vp, i32, vp, i32, i32, i32, ll, i32, vp],
     "av_sum_slices": [vp, i32, ll, ll, f32, vp, i32, vp],
     "av_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, ll, i32, f32, i32, vp],

@@ -12,6 +12,7 @@ parameter, so nothing below encoder layer 6 is ever differentiated (SURVEY §0.3
 """
 from __future__ import annotations
 
+import ctypes
 import json
 import os
 from types import SimpleNamespace
@@ -32,6 +33,12 @@ DROP_BITS = os.environ.get("AVAMD_ATTN_DROPBITS", "1") != "0"
 DROP_BITS_ALL = os.environ.get("AVAMD_ATTN_DROPBITS_ALL", "0") != "0"
 # FFN activation site saves its gradient factor instead of the pre-activation (bf16 mode); AVAMD_FFN_GF=0 = recompute gelu' and the mask in the backward
 FFN_GF = os.environ.get("AVAMD_FFN_GF", "1") != "0"
+# one native call per encoder layer forward (av_w2v2_layer_fwd) instead of seven per-kernel calls: same kernels, same arguments, fewer host round trips
+# - for the launch-bound regime only (at most NATIVE_MAX_ROWS tokens per pass: config 1's 2 x 1 s step 21.1 -> 17.8 ms); at the benchmark size the
+# device is the bottleneck and the burst of seven launches measured 0.9 % SLOWER (1001 / 1008 vs 1014 / 1015 utt/s, same box) - the per-kernel
+# calls there interleave better with the other pass's and the lip streams' launches.  AVAMD_W2V2_NATIVE=0 never, 2 always.
+NATIVE_LAYER = int(os.environ.get("AVAMD_W2V2_NATIVE", "1"))
+NATIVE_MAX_ROWS = 4096
 # the second audio pass of a step runs on its own stream beside the first (HBM-bound row kernels of one pass overlap MFMA-bound GEMMs of the other)
 PASS_STREAMS = os.environ.get("AVAMD_PASS_STREAMS", "1") != "0"
 
@@ -379,6 +386,12 @@ class Wav2Vec2ModelHIP(nn.Module):
         mid = torch.empty_like(h) if nl >= 10 else None
         saved = [None] * nl
         scale = hd ** -0.5
+        # one native call per layer (AVAMD_W2V2_NATIVE=0: one call per kernel; the per-kernel path also serves the fp32 parity mode and bench.py's
+        # probe legs, whose timing hooks live in ops.gemm / ops.attention_fwd)
+        native = (NATIVE_LAYER and (NATIVE_LAYER >= 2 or B * T <= NATIVE_MAX_ROWS) and is_lp(dtype) and dev.type == "cuda"
+                  and ops.GemmProbe.active is None and ops.AttnProbe.active is None and Hd % nh == 0)
+        if native and getattr(self, "_largs", None) is None:
+            self._largs = L.W2v2LayerArgs()
         for li in range(nl):
             if mid is not None and 6 <= li <= 9:
                 ops.axpby(0.25, h, 1.0 if li > 6 else 0.0, mid)                          # model/encoder.py:97-99 (the first term writes: no zero fill)
@@ -388,10 +401,51 @@ class Wav2Vec2ModelHIP(nn.Module):
                 if keep_ctx:
                     saved[li] = "skipped"
                 continue
+            amask = amasks.get(li)
+            if native:
+                # the layer's seven launches from ONE native call (csrc/w2v2_layer.hip: the same kernels with the same arguments)
+                if amask is not None and amask_evt is not None:
+                    evts, last_evt = amask_evt
+                    nxt = min((l for l in evts if l >= li), default=None)
+                    torch.cuda.current_stream(dev).wait_event(evts.pop(nxt) if nxt is not None else last_evt)
+                    for l in [l for l in evts if l < li]:
+                        evts.pop(l)
+                    if nxt is None:
+                        amask_evt = None
+                I = cfg["intermediate_size"]
+                M = B * T
+                x1 = torch.empty((B, T, Hd), dtype=dtype, device=dev); x2 = torch.empty((B, T, Hd), dtype=dtype, device=dev)
+                st4 = torch.empty((4, M), dtype=torch.float32, device=dev)
+                mu1, rs1, mu2, rs2 = st4[0], st4[1], st4[2], st4[3]
+                qkv = torch.empty((B, T, 3, nh, hd), dtype=dtype, device=dev)
+                ao = torch.empty((B, T, nh, hd), dtype=dtype, device=dev)
+                lse = torch.empty((B, nh, T), dtype=torch.float32, device=dev) if keep_ctx else None
+                h2 = torch.empty((B, T, Hd), dtype=torch.float32, device=dev); h3 = torch.empty((B, T, Hd), dtype=torch.float32, device=dev)
+                u = torch.empty((B, T, I), dtype=dtype, device=dev) if keep_ctx else None
+                g = torch.empty((B, T, I), dtype=dtype, device=dev)
+                gf = FFN_GF and keep_ctx
+                a = self._largs
+                a.B, a.T, a.hidden, a.heads, a.inter, a.lp, a.gf, a.stream_base = B, T, Hd, nh, I, L.AV_BF16, int(gf), li * 8
+                a.eps, a.scale, a.hd_p, a.at_p, a.ac_p, a.seed = eps, scale, hd_p, at_p, ac_p, seed
+                a.ln1_g = self.P(p + "layer_norm.weight").data.data_ptr(); a.ln1_b = self.P(p + "layer_norm.bias").data.data_ptr()
+                a.ln2_g = self.P(p + "final_layer_norm.weight").data.data_ptr(); a.ln2_b = self.P(p + "final_layer_norm.bias").data.data_ptr()
+                a.b_qkv = self.qkv_b(li).data_ptr(); a.b_o = self.P(p + "attention.out_proj.bias").data.data_ptr()
+                a.b_1 = self.P(p + "feed_forward.intermediate_dense.bias").data.data_ptr(); a.b_2 = self.P(p + "feed_forward.output_dense.bias").data.data_ptr()
+                a.w_qkv = self.qkv_w(li, dtype).data_ptr(); a.w_o = self.c(p + "attention.out_proj.weight", dtype).data_ptr()
+                a.w_1 = self.c(p + "feed_forward.intermediate_dense.weight", dtype).data_ptr(); a.w_2 = self.c(p + "feed_forward.output_dense.weight", dtype).data_ptr()
+                a.h, a.klen, a.amask = h.data_ptr(), ops.ptr(klen), ops.ptr(amask)
+                a.x1, a.qkv, a.ao, a.x2, a.u, a.g = x1.data_ptr(), qkv.data_ptr(), ao.data_ptr(), x2.data_ptr(), ops.ptr(u), g.data_ptr()
+                a.mu1, a.rs1, a.lse, a.h2, a.mu2, a.rs2, a.h3 = mu1.data_ptr(), rs1.data_ptr(), ops.ptr(lse), h2.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), h3.data_ptr()
+                L.check(L.lib().av_w2v2_layer_fwd(ctypes.byref(a), ops.stream()), "av_w2v2_layer_fwd")
+                if keep_ctx:
+                    tr = train[li]
+                    saved[li] = dict(h=h, mu1=mu1, rs1=rs1, qkv=qkv, ao=ao, lse=lse, amask=amask, h2=h2, mu2=mu2, rs2=rs2, u=u, gf=gf,
+                                     x1=x1 if tr else None, x2=x2 if tr else None, g=g if tr else None)
+                h = h3
+                continue
             x1, mu1, rs1 = ops.layernorm_fwd(h, self.P(p + "layer_norm.weight").data, self.P(p + "layer_norm.bias").data,
                                              out_dtype=dtype, eps=eps, save_stats=True)
             qkv = ops.linear(x1, self.qkv_w(li, dtype), self.qkv_b(li), out_dtype=dtype).view(B, T, 3, nh, hd)
-            amask = amasks.get(li)
             if amask is not None and amask_evt is not None:
                 evts, last_evt = amask_evt
                 nxt = min((l for l in evts if l >= li), default=None)           # the first recorded event at or after this layer's mask

@@ -1,4 +1,5 @@
 """GPU parity of the HIP modules (visual encoder, fusion incl. BiLSTM, CTC head, contrastive loss, Adam) vs the oracle."""
+import numpy as np
 import pytest
 import torch
 
@@ -440,3 +441,36 @@ def test_trainer_loss_scaling_step_equals_plain_step():
         for k in sa:
             tol = 2e-4 if k.endswith("k_proj.bias") else 3e-6
             assert float((sa[k].float() - sb[k].float()).abs().max()) < tol, k
+
+
+@pytest.mark.parametrize("regularize", [False, True])
+def test_native_layer_forward_equals_the_per_kernel_path(regularize):
+    """av_w2v2_layer_fwd (csrc/w2v2_layer.hip: the seven launches of an encoder layer's forward from one native call) against the per-kernel
+    path of model/w2v2.py on the same weights, input, seeds and LayerDrop draws: outputs, mid-layer average and every tensor saved for the
+    backward are bit-identical; the backward then gives bit-identical gradients."""
+    init = pkg("utils.init"); enc = pkg("model.encoder"); synth = pkg("dataset.synthetic"); w2 = pkg("model.w2v2")
+    pkg("precision").set_precision("bf16")
+    extra = dict(hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, layerdrop=0.2, mask_time_prob=0.05) if regularize else {}
+    outs = []
+    for native in (2, 0):                                       # 2 = always (the default takes it up to NATIVE_MAX_ROWS tokens per pass), 0 = never
+        w2.NATIVE_LAYER = native
+        try:
+            cfg = dict(init.W2V2_TINY, **extra)
+            ae = enc.AudioEncoder(cfg, freeze=True).cuda()
+            ae.load_state_dict(init.w2v2_state_dict(init.W2V2_TINY))
+            for n, p in ae.model.named_parameters():
+                p.requires_grad = any(f"encoder.layers.{i}." in n for i in range(6, 10))
+            ae.train()
+            batch = synth.make_batch(3, 1.2, seed=42, ragged=True)
+            torch.manual_seed(7); np.random.seed(11)            # dropout / LayerDrop draws: torch generators; SpecAugment: numpy's global RNG (as HF)
+            last, mid = ae(batch["audio"].cuda(), attention_mask=(batch["mask1"] != 3).cuda())
+            (last.float().square().mean() + 0.5 * mid.float().square().mean()).backward()
+            grads = {n: p.grad.clone() for n, p in ae.model.named_parameters() if p.grad is not None}
+            outs.append((last.detach().clone(), mid.detach().clone(), grads))
+        finally:
+            w2.NATIVE_LAYER = 1
+    (l0, m0, g0), (l1, m1, g1) = outs
+    assert torch.equal(l0, l1) and torch.equal(m0, m1)
+    assert g0.keys() == g1.keys() and len(g0) > 0
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
