@@ -366,6 +366,29 @@ typedef struct av_w2v2_layer_args {
 } av_w2v2_layer_args;
 int av_w2v2_layer_fwd(const av_w2v2_layer_args* args, void* stream);
 
+/* Backward of the same layer when its weights take no gradient (frozen layers above the lowest trainable one: the gradient only passes through):
+ * dh [M][hidden] fp32 = gradient of the layer's output h3; dh_lp = optional 16-bit copy of it with THIS layer's FFN-output dropout mask already
+ * applied (written by the LayerNorm backward of the layer above; NULL: the entry point makes it in dh3_t).  Saved tensors of av_w2v2_layer_fwd:
+ * h, mu1, rs1, qkv, ao, lse, amask, h2, mu2, rs2, u (+ gf).  Weights TRANSPOSED to the K-contiguous form of the dX products, 16-bit:
+ * w_2t [inter][hidden] = output_dense^T, w_1t [hidden][inter] = intermediate_dense^T, w_ot [hidden][hidden] = out_proj^T, w_qkvt [hidden][3 hidden].
+ * Work / output buffers (caller-allocated): du [M][inter], dx2, dh2_lp, dao, dx1 [M][hidden], dqkv [M][3 hidden] 16-bit; dh2, dh_out [M][hidden] fp32;
+ * delta [B][heads][T] fp32; dh_out_lp (optional) = 16-bit copy of dh_out with the dropout mask of stream `lower_stream` (the FFN-output site of the
+ * layer below) applied.  Same kernels, same arguments as the per-kernel path of model/w2v2.py::_layer_backward: bit-identical. */
+typedef struct av_w2v2_layer_bwd_args {
+    int B, T, hidden, heads, inter;
+    int lp, gf, stream_base, lower_stream;
+    float scale, hd_p, at_p, ac_p;
+    unsigned long long seed;
+    const float *ln1_g, *ln2_g;
+    const void *w_2t, *w_1t, *w_ot, *w_qkvt;
+    const float *dh, *h, *mu1, *rs1, *lse, *h2, *mu2, *rs2;
+    const void *dh_lp, *qkv, *ao, *amask, *u;
+    const int* klen;
+    void *dh3_t, *du, *dx2, *dh2_lp, *dao, *dqkv, *dx1, *dh_out_lp;
+    float *dh2, *delta, *dh_out;
+} av_w2v2_layer_bwd_args;
+int av_w2v2_layer_bwd_dx(const av_w2v2_layer_bwd_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

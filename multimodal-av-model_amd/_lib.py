@@ -51,12 +51,28 @@ class W2v2LayerArgs(C.Structure):
     ]
 
 
+class W2v2LayerBwdArgs(C.Structure):
+    _fields_ = [
+        ("B", i32), ("T", i32), ("hidden", i32), ("heads", i32), ("inter", i32), ("lp", i32), ("gf", i32), ("stream_base", i32), ("lower_stream", i32),
+        ("scale", f32), ("hd_p", f32), ("at_p", f32), ("ac_p", f32),
+        ("seed", C.c_ulonglong),
+        ("ln1_g", vp), ("ln2_g", vp),
+        ("w_2t", vp), ("w_1t", vp), ("w_ot", vp), ("w_qkvt", vp),
+        ("dh", vp), ("h", vp), ("mu1", vp), ("rs1", vp), ("lse", vp), ("h2", vp), ("mu2", vp), ("rs2", vp),
+        ("dh_lp", vp), ("qkv", vp), ("ao", vp), ("amask", vp), ("u", vp),
+        ("klen", vp),
+        ("dh3_t", vp), ("du", vp), ("dx2", vp), ("dh2_lp", vp), ("dao", vp), ("dqkv", vp), ("dx1", vp), ("dh_out_lp", vp),
+        ("dh2", vp), ("delta", vp), ("dh_out", vp),
+    ]
+
+
 # name -> argtypes (restype is int status unless listed in _RESTYPES); must list every symbol of include/av_hip.h
 SIGNATURES = {
     "av_last_error": [],
     "av_version": [],
     "av_gemm": [C.POINTER(GemmArgs), vp],
     "av_w2v2_layer_fwd": [C.POINTER(W2v2LayerArgs), vp],
+    "av_w2v2_layer_bwd_dx": [C.POINTER(W2v2LayerBwdArgs), vp],
     "av_transpose": [vp, i32, vp, i32, i32, i32, ll, i32, vp],
     "av_sum_slices": [vp, i32, ll, ll, f32, vp, i32, vp],
     "av_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, ll, i32, f32, i32, vp],

@@ -9,12 +9,12 @@
 namespace {
 
 int linear(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int lp, int out_dtype, int act, const float* R, void* C2,
-           float drop_p, unsigned long long seed, unsigned stream_id, void* stream) {
+           float drop_p, unsigned long long seed, unsigned stream_id, void* stream, const void* aux = nullptr) {
     av_gemm_args a = {};
-    a.A = x; a.B = w; a.C = y; a.C2 = C2; a.bias = bias; a.R = R;
+    a.A = x; a.B = w; a.C = y; a.C2 = C2; a.bias = bias; a.R = R; a.aux = aux;
     a.M = M; a.N = N; a.K = K; a.batch = 1;
     a.lda = K; a.ldb = K; a.ldc = N; a.ldr = N;
-    a.a_mode = 0; a.b_mode = 0; a.in_dtype = lp; a.out_dtype = out_dtype; a.aux_dtype = 0; a.act = act;
+    a.a_mode = 0; a.b_mode = 0; a.in_dtype = lp; a.out_dtype = out_dtype; a.aux_dtype = aux ? lp : 0; a.act = act;
     a.alpha = 1.0f;
     if (drop_p > 0.f) { a.drop_p = drop_p; a.drop_seed = seed; a.drop_stream = stream_id; }
     return av_gemm(&a, stream);
@@ -47,4 +47,51 @@ extern "C" int av_w2v2_layer_fwd(const av_w2v2_layer_args* p, void* stream) {
                      (unsigned)(p->stream_base + 1), stream)))
         return rc;
     return linear(p->g, p->w_2, p->b_2, p->h3, M, Hd, p->inter, p->lp, AV_F32, AV_ACT_NONE, p->h2, nullptr, p->hd_p, p->seed, (unsigned)(p->stream_base + 2), stream);
+}
+
+// The backward of the same layer for a layer WITHOUT weight gradients (frozen weights: the gradient only passes through - 25 of the 32 layer
+// backwards of a benchmark step): saved-factor / GELU-gradient dX of the FFN, LayerNorm backward (+ the 16-bit copy with the next dropout site's
+// mask), output-projection dX, attention backward, QKV dX, LayerNorm backward - the launches of model/w2v2.py::_layer_backward with tr = False.
+extern "C" int av_w2v2_layer_bwd_dx(const av_w2v2_layer_bwd_args* p, void* stream) {
+    AV_CHECK(p && p->dh && p->h && p->h2 && p->qkv && p->ao && p->lse && p->u && p->du && p->dx2 && p->dh2 && p->dh2_lp && p->dao && p->dqkv && p->delta &&
+             p->dx1 && p->dh_out, "av_w2v2_layer_bwd_dx: null pointer");
+    AV_CHECK(p->dh_lp || p->dh3_t, "av_w2v2_layer_bwd_dx: neither a 16-bit copy of dh nor a buffer to make one");
+    AV_CHECK(p->lp == AV_BF16 && p->hidden % p->heads == 0, "av_w2v2_layer_bwd_dx: 16-bit compute type only; hidden %% heads == 0");
+    const int M = p->B * p->T, Hd = p->hidden, I = p->inter, hd = Hd / p->heads;
+    const long long es = 2;
+    int nblk = (M + 15) / 16;                                    // ops.layernorm_bwd's block count: max(1, min(512, ceil(rows / 16)))
+    nblk = nblk > 512 ? 512 : (nblk < 1 ? 1 : nblk);
+    int rc;
+    const void* dh3_t = p->dh_lp;
+    if (!dh3_t) {                                                // the FFN-output dropout site of THIS layer, applied to the incoming gradient
+        rc = p->hd_p > 0.f ? av_cast_dropout(p->dh, AV_F32, p->dh3_t, p->lp, (long long)M * Hd, p->hd_p, p->seed, (unsigned)(p->stream_base + 2), stream)
+                           : av_cast(p->dh, AV_F32, p->dh3_t, p->lp, (long long)M * Hd, stream);
+        if (rc) return rc;
+        dh3_t = p->dh3_t;
+    }
+    // du = (dh3 W2) o saved factor   |   o gelu'(u) o activation-dropout mask
+    if ((rc = linear(dh3_t, p->w_2t, nullptr, p->du, M, I, Hd, p->lp, p->lp, p->gf ? AV_ACT_MUL_AUX : AV_ACT_MUL_GELU_GRAD, nullptr, nullptr,
+                     p->gf ? 0.f : p->ac_p, p->seed, (unsigned)(p->stream_base + 1), stream, p->u)))
+        return rc;
+    if ((rc = linear(p->du, p->w_1t, nullptr, p->dx2, M, Hd, I, p->lp, p->lp, AV_ACT_NONE, nullptr, nullptr, 0.f, 0, 0, stream))) return rc;
+    rc = p->hd_p > 0.f ? av_layernorm_bwd_drop(p->h2, AV_F32, p->dx2, p->lp, p->ln2_g, p->mu2, p->rs2, p->dh, p->dh2, nullptr, nblk, M, Hd, p->dh2_lp, p->hd_p, p->seed,
+                                              (unsigned)(p->stream_base + 0), stream)
+                       : av_layernorm_bwd(p->h2, AV_F32, p->dx2, p->lp, p->ln2_g, p->mu2, p->rs2, p->dh, p->dh2, nullptr, nblk, M, Hd, p->dh2_lp, stream);
+    if (rc) return rc;
+    if ((rc = linear(p->dh2_lp, p->w_ot, nullptr, p->dao, M, Hd, Hd, p->lp, p->lp, AV_ACT_NONE, nullptr, nullptr, 0.f, 0, 0, stream))) return rc;
+    {
+        const char* q = (const char*)p->qkv;
+        char* dq = (char*)p->dqkv;
+        const long long bs3 = (long long)p->T * 3 * Hd, rs3 = 3LL * Hd, bs1 = (long long)p->T * Hd, rs1 = Hd;
+        const long long st[16] = {bs3, rs3, bs3, rs3, bs3, rs3, bs1, rs1, bs1, rs1, bs3, rs3, bs3, rs3, bs3, rs3};     // q k v o do dq dk dv
+        if ((rc = av_attention_bwd_mask(q, q + (long long)Hd * es, q + 2LL * Hd * es, p->ao, p->dao, p->lse, p->delta, dq, dq + (long long)Hd * es, dq + 2LL * Hd * es,
+                                        p->B, p->heads, p->T, p->T, hd, st, p->klen, p->scale, p->at_p, p->seed, (unsigned)(p->stream_base + 3),
+                                        p->at_p > 0.f ? p->amask : nullptr, stream)))
+            return rc;
+    }
+    if ((rc = linear(p->dqkv, p->w_qkvt, nullptr, p->dx1, M, Hd, 3 * Hd, p->lp, p->lp, AV_ACT_NONE, nullptr, nullptr, 0.f, 0, 0, stream))) return rc;
+    if (p->dh_out_lp && p->hd_p > 0.f)
+        return av_layernorm_bwd_drop(p->h, AV_F32, p->dx1, p->lp, p->ln1_g, p->mu1, p->rs1, p->dh2, p->dh_out, nullptr, nblk, M, Hd, p->dh_out_lp, p->hd_p, p->seed,
+                                     (unsigned)p->lower_stream, stream);
+    return av_layernorm_bwd(p->h, AV_F32, p->dx1, p->lp, p->ln1_g, p->mu1, p->rs1, p->dh2, p->dh_out, nullptr, nblk, M, Hd, p->dh_out_lp, stream);
 }

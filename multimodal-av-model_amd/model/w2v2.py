@@ -592,6 +592,40 @@ class Wav2Vec2ModelHIP(nn.Module):
             ar = self._arenas[li] = GradArena()
         dev_ = ctx["hL"].device
 
+        if (not tr and fuse_lp and NATIVE_LAYER and (NATIVE_LAYER >= 2 or M <= NATIVE_MAX_ROWS) and dev_.type == "cuda"
+                and ops.GemmProbe.active is None and ops.AttnProbe.active is None):
+            # a layer whose weights take no gradient: its eight launches from ONE native call (csrc/w2v2_layer.hip: av_w2v2_layer_bwd_dx)
+            wt = [ops.transpose_cached(w) for w in (self.c(p + "feed_forward.output_dense.weight", dtype), self.c(p + "feed_forward.intermediate_dense.weight", dtype),
+                                                    self.c(p + "attention.out_proj.weight", dtype), self.qkv_w(li, dtype))]
+            if all(w is not None for w in wt):
+                lower = li - 1
+                lp_ok = hd_p == 0 or (lower >= ctx["first"] and not isinstance(ctx["saved"][lower], str) and not (dmid_c is not None and 6 <= lower + 1 <= 9))
+                lp_in = dh_lp if dh_lp is not None else None
+                e16 = lambda *shape: torch.empty(shape, dtype=dtype, device=dev_)
+                dh3_t = None if lp_in is not None else e16(M, Hd)
+                du, dx2, dh2_lp, dao, dqkv, dx1 = e16(M, I), e16(M, Hd), e16(M, Hd), e16(M, Hd), e16(B, T, 3, nh, hd), e16(M, Hd)
+                dh2 = torch.empty((B, T, Hd), dtype=torch.float32, device=dev_); dh_new = torch.empty((B, T, Hd), dtype=torch.float32, device=dev_)
+                delta = torch.empty((B, nh, T), dtype=torch.float32, device=dev_)
+                dh_new_lp = e16(B, T, Hd) if lp_ok else None
+                a = getattr(self, "_lbargs", None)
+                if a is None:
+                    a = self._lbargs = L.W2v2LayerBwdArgs()
+                a.B, a.T, a.hidden, a.heads, a.inter, a.lp, a.gf, a.stream_base, a.lower_stream = B, T, Hd, nh, I, L.AV_BF16, int(bool(s.get("gf"))), li * 8, lower * 8 + 2
+                a.scale, a.hd_p, a.at_p, a.ac_p, a.seed = scale, hd_p, at_p, ac_p, seed
+                a.ln1_g = self.P(p + "layer_norm.weight").data.data_ptr(); a.ln2_g = self.P(p + "final_layer_norm.weight").data.data_ptr()
+                a.w_2t, a.w_1t, a.w_ot, a.w_qkvt = (w.data_ptr() for w in wt)
+                a.dh, a.h, a.mu1, a.rs1, a.lse = dh.data_ptr(), s["h"].data_ptr(), s["mu1"].data_ptr(), s["rs1"].data_ptr(), s["lse"].data_ptr()
+                a.h2, a.mu2, a.rs2 = s["h2"].data_ptr(), s["mu2"].data_ptr(), s["rs2"].data_ptr()
+                a.dh_lp, a.qkv, a.ao, a.amask, a.u = ops.ptr(lp_in), s["qkv"].data_ptr(), s["ao"].data_ptr(), ops.ptr(s["amask"]), s["u"].data_ptr()
+                a.klen = ops.ptr(ctx["klen"])
+                a.dh3_t, a.du, a.dx2, a.dh2_lp, a.dao, a.dqkv, a.dx1, a.dh_out_lp = (ops.ptr(dh3_t), du.data_ptr(), dx2.data_ptr(), dh2_lp.data_ptr(), dao.data_ptr(),
+                                                                                   dqkv.data_ptr(), dx1.data_ptr(), ops.ptr(dh_new_lp))
+                a.dh2, a.delta, a.dh_out = dh2.data_ptr(), delta.data_ptr(), dh_new.data_ptr()
+                L.check(L.lib().av_w2v2_layer_bwd_dx(ctypes.byref(a), ops.stream()), "av_w2v2_layer_bwd_dx")
+                ctx["saved"][li] = None
+                st["dh"], st["dh_lp"] = dh_new, dh_new_lp
+                return
+
         def wgrad(key, dy, x):                                       # dW (+)= dy^T x; the first writer of a step writes into the layer's flat bucket
             if key in grads:
                 ops.matmul_tn(dy, x, out=grads[key], accumulate=True)
