@@ -2,6 +2,8 @@
 status codes + av_last_error() (no kernel is launched without a GPU)."""
 import ctypes
 import os
+
+import pytest
 import re
 
 from conftest import ROOT, pkg
@@ -60,17 +62,34 @@ def test_errors_are_reported_not_aborted():
         assert "libavhip demo failed" in str(e)
 
 
-def test_gemm_args_struct_matches_header_layout():
-    """The ctypes mirror must have the same field order as `struct av_gemm_args`."""
-    L = pkg("_lib")
+def _header_fields(name):
+    """(field, is_pointer, C scalar type) of `typedef struct <name> { ... }` in include/av_hip.h, in declaration order."""
     txt = open(os.path.join(ROOT, "include", "av_hip.h"), encoding="utf-8").read()
-    body = txt[txt.index("typedef struct av_gemm_args {"):txt.index("} av_gemm_args;")]
+    body = txt[txt.index("typedef struct %s {" % name):txt.index("} %s;" % name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = []
+    out = []
     for stmt in body.split("{", 1)[1].split(";"):
         stmt = stmt.strip()
         if not stmt:
             continue
-        stmt = re.sub(r"^(const\s+)?(unsigned\s+long\s+long|unsigned\s+int|long\s+long|void|float|int)\s*\*?", "", stmt).strip()
-        fields += [f.strip().lstrip("*").strip() for f in stmt.split(",")]
-    assert fields == [f[0] for f in L.GemmArgs._fields_], (fields, [f[0] for f in L.GemmArgs._fields_])
+        m = re.match(r"^(const\s+)?(unsigned\s+long\s+long|unsigned\s+int|long\s+long|void|float|int)\s*(\*?)", stmt)
+        base, first_ptr = m.group(2), bool(m.group(3))
+        rest = stmt[m.end():].strip()
+        for k, f in enumerate(rest.split(",")):
+            f = f.strip()
+            out.append((f.lstrip("*").strip(), f.startswith("*") or (k == 0 and first_ptr), base))
+    return out
+
+
+@pytest.mark.parametrize("cname,pyname", [("av_gemm_args", "GemmArgs"), ("av_w2v2_layer_args", "W2v2LayerArgs"), ("av_w2v2_layer_bwd_args", "W2v2LayerBwdArgs")])
+def test_args_structs_match_the_header_layout(cname, pyname):
+    """The ctypes mirrors must have the field order AND the field kinds (pointer / int / float / 64-bit) of the structs in include/av_hip.h."""
+    import ctypes as C
+    L = pkg("_lib")
+    hdr = _header_fields(cname)
+    mirror = getattr(L, pyname)._fields_
+    assert [f[0] for f in hdr] == [f[0] for f in mirror], ([f[0] for f in hdr], [f[0] for f in mirror])
+    kinds = {"int": C.c_int, "float": C.c_float, "long long": C.c_longlong, "unsigned long long": C.c_ulonglong, "unsigned int": C.c_uint}
+    for (name, is_ptr, base), (_, ctype) in zip(hdr, mirror):
+        want = C.c_void_p if is_ptr else kinds[base]
+        assert C.sizeof(ctype) == C.sizeof(want) and (ctype is C.c_void_p) == is_ptr, (cname, name, ctype, want)

@@ -204,3 +204,18 @@ def test_checkpoint_round_trip_reference_layout(tmp_path):
     torch.save({"epoch": 1}, path)
     with pytest.raises(KeyError):
         ck.load_checkpoint(b, path)
+
+
+def test_split_k_policies_cover_k_and_fill_the_chip():
+    """ops._split_k8 (slices for the 8-phase kernel's k-major dW form): whole 64-wide K-tiles per slice, the slices cover K, at least 512 k per
+    slice when split, and the step's shapes land on one round of 256 workgroups."""
+    ops = pkg("ops")
+    for tiles, Kk, mn in [(48, 12736, 3072 * 1024), (64, 12736, 4096 * 1024), (64, 12736, 1024 * 4096), (16, 12736, 1024 * 1024), (4, 199, 512 * 512),
+                          (64, 6368, 4096 * 1024), (1, 70000, 256 * 256)]:
+        S, chunk = ops._split_k8(tiles, Kk, mn)
+        assert S >= 1 and (S == 1 or (chunk % 64 == 0 and chunk >= 512))
+        assert S * chunk >= Kk and (S - 1) * chunk < Kk
+    S, chunk = ops._split_k8(64, 12736, 4096 * 1024)
+    assert 64 * S == 256 and chunk == 3200                      # FFN weight gradients: 64 tiles x 4 slices of 50 K-tiles
+    S, _ = ops._split_k8(48, 12736, 3072 * 1024)
+    assert 200 <= 48 * S <= 256                                 # QKV weight gradient: one round
