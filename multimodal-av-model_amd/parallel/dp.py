@@ -98,12 +98,16 @@ class GradBucketReducer:
             self.stream = torch.cuda.Stream(device=dev)
         return self.stream
 
-    def _issue(self, flat: torch.Tensor) -> None:
+    def _issue(self, flat: torch.Tensor, also_after=()) -> None:
+        """``also_after``: further streams whose enqueued work writes ``flat`` (the second audio pass's stream): the collective waits for them
+        too - the CURRENT stream does not have to."""
         self.bucket_bytes.append(flat.numel() * flat.element_size())
         if self.world > 1 or self.always:
             if flat.is_cuda and self._use_side:
                 s = self._side(flat.device)
                 s.wait_stream(torch.cuda.current_stream(flat.device))
+                for x in also_after:
+                    s.wait_stream(x)
                 with torch.cuda.stream(s):
                     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 flat.record_stream(s)
@@ -112,10 +116,15 @@ class GradBucketReducer:
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self.pending.append((work, flat, None))
 
-    def reduce_flat(self, arena: GradArena) -> None:
+    def reduce_flat(self, arena: GradArena, also_after=()) -> None:
         """All-reduce (SUM) of a bucket whose gradients already live in one flat buffer: in place, nothing is copied."""
         self.flat_reduces += 1
-        self._issue(arena.flat)
+        if (self.world > 1 or self.always) and arena.flat.is_cuda and self._use_side:
+            self._issue(arena.flat, also_after)
+        else:                                                    # collective on the current stream: it has to see the other streams' work itself
+            for x in also_after:
+                torch.cuda.current_stream(arena.flat.device).wait_stream(x)
+            self._issue(arena.flat)
 
     def reduce_async(self, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
         """Pack ``tensors`` into one flat bucket, start its all-reduce (SUM), return views of the bucket that alias
