@@ -191,6 +191,12 @@ def main():
         local = 0
         # rehearsal only: the ranks share ONE GPU, where the persistent BiLSTM kernels of two processes cannot all be resident at once
         os.environ.setdefault("AVAMD_LSTM_PERSISTENT", "0")
+    if (world > 1 or args.force_dp) and args.backend == "nccl":
+        # The step's five streams want FOUR hardware queues to themselves (profiles/r04_hw_queues.txt: 5+ active queues cost 15 %, the ROCm default of 4 is
+        # the optimum without a communicator); an initialised RCCL communicator takes two of the process's queues, and the one-rank leg measured
+        # 66.3 / 65.6 / 64.7 / 74 ms per step at 4 / 5 / 6 / 8 queues against 64.4 without a communicator.  Read by the runtime when the device is first
+        # touched (below); an explicit setting of the caller wins.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1 or args.force_dp:
@@ -216,7 +222,7 @@ def main():
         chk = torch.full((1024,), float(rank + 1), device=dev)
         dist.all_reduce(chk)
         torch.cuda.synchronize()
-        dp_probe = {"rccl_ranks": dist.get_world_size(), "allreduce_checksum": float(chk.sum()),
+        dp_probe = {"rccl_ranks": dist.get_world_size(), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "allreduce_checksum": float(chk.sum()),
                     "allreduce_checksum_expected": 1024.0 * world * (world + 1) / 2}
     ae = t.audio_encoder
     T_audio, T_v, T_enc = batch["_T_audio"], batch["_T_v"], batch["_T_enc"]
